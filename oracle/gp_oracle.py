@@ -1,0 +1,261 @@
+"""
+CPU oracle for the stpy GP dense-linear-algebra hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of what the reference (Mojusko/stpy @ 2024-11-01) computes on
+the path named by BASELINE.json:north_star.  It is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing
+under ``stpy_amd/`` imports it and the product path never falls back to it.
+
+Parity status: PINNED.  Every function below is checked against golden vectors captured from the
+real reference imported in the authoring container (``tests/golden/make_golden.py`` ->
+``tests/golden/*.npz``; see ``tests/test_oracle_golden.py``).  The reference's own ``tests/`` hold
+no assertions or fixtures, so those captured outputs are the only pin.
+
+Each function cites the reference lines it follows (paths relative to the reference root).
+
+Numerical note: the reference solves with ``torch.linalg.lstsq`` / LU / ``slogdet``
+(gauss_procc.py:367-378, :631-638); mathematically that is the SPD solve restated here with a
+Cholesky factor (the explicit-Cholesky form the reference itself uses in estimator.py:32-40).
+"""
+import math
+
+import numpy as np
+import scipy.linalg as sla
+from scipy.spatial.distance import cdist
+
+SQRT3 = math.sqrt(3.0)
+SQRT5 = math.sqrt(5.0)
+
+
+# --------------------------------------------------------------------------------------------
+# kernel functions  (stpy/kernels.py)
+# --------------------------------------------------------------------------------------------
+
+def _cols(a, group):
+	a = np.asarray(a, dtype=np.float64)
+	if group is None:
+		return a
+	return a[:, list(group)]
+
+
+def squared_exponential(a, b, gamma=1.0, kappa=1.0, group=None):
+	"""kernels.py:368-398 -- norm expansion, no clamp of the squared distance; returns (|b|,|a|)."""
+	a = _cols(a, group)
+	b = _cols(b, group)
+	normx = np.sum(a ** 2, axis=1).reshape(-1, 1)
+	normy = np.sum(b ** 2, axis=1).reshape(-1, 1)
+	product = b @ a.T
+	sqdist = -2 * product + normx.T + normy
+	arg = (-0.5 / (gamma * gamma)) * sqdist
+	return kappa * np.exp(arg)
+
+
+def ard(a, b, ard_gamma, kappa=1.0, group=None):
+	"""kernels.py:552-583 -- columns scaled by 1/ard_gamma[group], then SE with gamma = 1."""
+	ard_gamma = np.asarray(ard_gamma, dtype=np.float64).reshape(-1)
+	a = _cols(a, group)
+	b = _cols(b, group)
+	g = ard_gamma if group is None else ard_gamma[list(group)]
+	a = a / g
+	b = b / g
+	normx = np.sum(a ** 2, axis=1).reshape(-1, 1)
+	normy = np.sum(b ** 2, axis=1).reshape(-1, 1)
+	sqdist = -2 * (b @ a.T) + normx.T + normy
+	return kappa * np.exp(-0.5 * sqdist)
+
+
+def _matern_of_dist(dists, nu):
+	"""kernels.py:844-851 (same expressions at :946-962)."""
+	if nu == 0.5:
+		return np.exp(-dists)
+	if nu == 1.5:
+		K = dists * SQRT3
+		return (1. + K) * np.exp(-K)
+	if nu == 2.5:
+		K = dists * SQRT5
+		return (1. + K + K ** 2 / 3.0) * np.exp(-K)
+	raise NotImplementedError("general-nu Bessel Matern is out of scope (SURVEY.md section 2, row 1)")
+
+
+def matern(a, b, gamma=1.0, nu=1.5, kappa=1.0, group=None):
+	"""kernels.py:811-859 -- scipy cdist of a/gamma, b/gamma (direct differences)."""
+	a = _cols(a, group)
+	b = _cols(b, group)
+	dists = cdist(a / gamma, b / gamma, metric='euclidean').T
+	return kappa * _matern_of_dist(dists, nu)
+
+
+def ard_matern(a, b, ard_gamma, nu=1.5, kappa=1.0, group=None):
+	"""kernels.py:917-970 -- scale by 1/ard_gamma[group] first (mm with a diagonal), then the
+	column subset, then torch.cdist."""
+	ard_gamma = np.asarray(ard_gamma, dtype=np.float64).reshape(-1)
+	a = np.asarray(a, dtype=np.float64)
+	b = np.asarray(b, dtype=np.float64)
+	g = ard_gamma if group is None else ard_gamma[list(group)]
+	a = a / g  # reference multiplies by diag(1/g): requires a.shape[1] == len(group)
+	b = b / g
+	a = _cols(a, group)
+	b = _cols(b, group)
+	dists = cdist(a, b, metric='euclidean').T
+	return kappa * _matern_of_dist(dists, nu)
+
+
+def linear(a, b, kappa=1.0, offset=0.0, group=None):
+	"""kernels.py:300-320."""
+	a = _cols(a, group)
+	b = _cols(b, group)
+	return kappa * (b @ a.T) + offset
+
+
+_KERNELS = {
+	"squared_exponential": lambda a, b, p: squared_exponential(a, b, p.get("gamma", 1.0), p.get("kappa", 1.0), p.get("group")),
+	"ard": lambda a, b, p: ard(a, b, p["ard_gamma"], p.get("kappa", 1.0), p.get("group")),
+	"matern": lambda a, b, p: matern(a, b, p.get("gamma", 1.0), p.get("nu", 1.5), p.get("kappa", 1.0), p.get("group")),
+	"ard_matern": lambda a, b, p: ard_matern(a, b, p["ard_gamma"], p.get("nu", 1.5), p.get("kappa", 1.0), p.get("group")),
+	"linear": lambda a, b, p: linear(a, b, p.get("kappa", 1.0), p.get("offset", 0.0), p.get("group")),
+}
+
+
+def kernel(a, b, spec, overrides=None):
+	"""
+	Composite kernel evaluation, kernels.py:136-159.
+
+	spec: list of (kernel_name, params_dict, op) with op in {"-", "+", "*"}; the first entry's op
+	is "-" (kernels.py:74).  overrides: {'0': {...}, '1': {...}} replaces the stored params of an
+	item *wholesale* except that 'group' is re-injected (kernels.py:105-110, :138-144) -- the
+	per-kernel functions then fall back to the constructor values for missing keys.
+	"""
+	out = None
+	for i, (name, params, op) in enumerate(spec):
+		p = dict(params)
+		if overrides:
+			p.update(overrides.get(str(i), {}))
+		k = _KERNELS[name](a, b, p)
+		if op == "+":
+			out = out + k
+		elif op == "*":
+			out = out * k
+		else:
+			out = k
+	return out
+
+
+# --------------------------------------------------------------------------------------------
+# GP fit / predict / log-marginal  (stpy/continuous_processes/gauss_procc.py, stpy/estimator.py)
+# --------------------------------------------------------------------------------------------
+
+def gram_train(x, spec, s, overrides=None):
+	"""gauss_procc.py:151-163 -- K = k(x,x) + Sigma^T Sigma with Sigma = s*I  ==  k(x,x) + s^2 I."""
+	K = kernel(x, x, spec, overrides)
+	K[np.diag_indices_from(K)] += s * s
+	return K
+
+
+def fit(x, y, spec, s):
+	"""gauss_procc.py:136-177 + :375-376 -- returns (L, alpha) with K = L L^T, alpha = K^-1 y."""
+	K = gram_train(x, spec, s)
+	L = sla.cholesky(K, lower=True, check_finite=False)
+	alpha = sla.cho_solve((L, True), np.asarray(y, dtype=np.float64).reshape(-1, 1), check_finite=False)
+	return L, alpha
+
+
+def mean_std(x, L, alpha, xtest, spec):
+	"""
+	gauss_procc.py:336-401 (squared loss, full=False): mu = K* alpha; sigma = sqrt(diag k(x*,x*) -
+	diag(K* K^-1 K*^T)).  No clamp of the variance (gauss_procc.py:394-395).
+	"""
+	Ks = kernel(x, xtest, spec)                      # (M, N)   :346
+	kdiag = kernel_diag(xtest, spec)                 # :347
+	mu = Ks @ alpha                                  # :381
+	V = sla.solve_triangular(L, Ks.T, lower=True, check_finite=False)   # (N, M)
+	var = kdiag - np.sum(V * V, axis=0)              # :391-394
+	with np.errstate(invalid="ignore"):
+		std = np.sqrt(var)
+	return mu.reshape(-1, 1), std.reshape(-1, 1)
+
+
+def mean_cov(x, L, alpha, xtest, spec):
+	"""gauss_procc.py:396-399 (full=True): (mu, K** - K* K^-1 K*^T)."""
+	Ks = kernel(x, xtest, spec)
+	Kss = kernel(xtest, xtest, spec)
+	mu = Ks @ alpha
+	V = sla.solve_triangular(L, Ks.T, lower=True, check_finite=False)
+	return mu.reshape(-1, 1), Kss - V.T @ V
+
+
+def kernel_diag(xtest, spec):
+	"""gauss_procc.py:347 -- the reference loops kernel(x_i, x_i) over test points."""
+	xtest = np.asarray(xtest, dtype=np.float64)
+	out = np.empty(xtest.shape[0])
+	# row-at-a-time exactly like the reference (cheap for oracle-sized M); vectorised per chunk
+	for i0 in range(0, xtest.shape[0], 1024):
+		blk = xtest[i0:i0 + 1024]
+		out[i0:i0 + 1024] = np.array([kernel(blk[i:i + 1], blk[i:i + 1], spec)[0, 0] for i in range(blk.shape[0])])
+	return out
+
+
+def prior_std(xtest, spec):
+	"""gauss_procc.py:349-363 -- unfitted branch: (0, sqrt(diag K**))."""
+	return np.zeros((xtest.shape[0], 1)), np.sqrt(kernel_diag(xtest, spec)).reshape(-1, 1)
+
+
+def log_marginal(x, y, spec, s, overrides=None, weight=1.0):
+	"""
+	gauss_procc.py:631-638 == estimator.py:32-40:  1/2 y^T K^-1 y + 1/2 * weight * log det K,
+	K = k_theta(x,x) + s^2 I.  *Negative* log evidence, no n/2 log(2 pi).  Shape (1,1).
+	"""
+	K = gram_train(x, spec, s, overrides)
+	L = sla.cholesky(K, lower=True, check_finite=False)
+	y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+	z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+	logdet = 2.0 * np.sum(np.log(np.diag(L)))
+	return np.array([[0.5 * float((z.T @ z)[0, 0]) + 0.5 * weight * logdet]])
+
+
+# --------------------------------------------------------------------------------------------
+# Random Fourier features  (stpy/embeddings/embedding.py)
+# --------------------------------------------------------------------------------------------
+
+def rff_embed(x, W, m, kappa=1.0, b=None):
+	"""
+	embedding.py:225-241.  Unbiased: columns j < m/2 are sqrt(2/m) cos(w_j.x) and columns
+	j >= m/2 are sqrt(2/m) sin(w_j.x) -- the sin half uses frequency rows m/2..m-1, *not* the cos
+	rows again; result (n, m).  Biased: sqrt(2/m) cos(w_j.x + b_j); the reference transposes that
+	branch twice (embedding.py:232 and :241), so the biased result has shape (m, n) -- kept.
+	Result times sqrt(kappa).
+	"""
+	x = np.asarray(x, dtype=np.float64)
+	W = np.asarray(W, dtype=np.float64)
+	d = x.shape[1]
+	q = W[:, 0:d] @ x.T                                  # (m, n)
+	c = np.sqrt(2. / float(m))
+	if b is not None:
+		z = (c * np.cos(q + np.asarray(b, dtype=np.float64).reshape(m, 1))).T
+	else:
+		h = int(m / 2)
+		z = np.concatenate([c * np.cos(q[0:h, :]), c * np.sin(q[h:m, :])])
+	return z.T * np.sqrt(kappa)
+
+
+def rff_sample_W(gamma, m, d, rng_state=None):
+	"""embedding.py:159,191,216 -- SE spectral density: W = N(0,1)^{m x d} / gamma (global numpy RNG)."""
+	if rng_state is not None:
+		np.random.seed(rng_state)
+	return np.random.normal(size=(m, d)) * (1. / gamma)
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic workloads shared by tests and bench  
+# --------------------------------------------------------------------------------------------
+
+def simple_1d_function(X):
+	"""test_functions/benchmarks.py:478-482."""
+	z = (X + 0.5) * 1.2
+	return -(1.4 - 3 * z) * np.sin(18 * z)
+
+
+def interval(n, d, L_infinity_ball=1.0):
+	"""helpers/helper.py:27-59,125-136 -- cartesian grid of linspace(-L, L, n) per dimension."""
+	arrays = [np.linspace(-L_infinity_ball, L_infinity_ball, n) for _ in range(d)]
+	mesh = np.meshgrid(*arrays, indexing="ij")
+	return np.stack([m.reshape(-1) for m in mesh], axis=1)

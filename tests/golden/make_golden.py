@@ -1,0 +1,299 @@
+"""
+Golden-vector generator: runs the REAL reference (Mojusko/stpy, read-only at /root/reference) in the
+authoring container and stores inputs + the reference's outputs as small .npz fixtures.
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The fixtures (data only: inputs and expected outputs) are committed; the reference itself never is
+and never travels to the GPU box.  Nothing at test/bench/smoke time reads /root/reference.
+
+Import notes:
+* ``stpy.kernels`` and ``stpy.embeddings.embedding`` import as they are.  Cases K*, R* below are
+  produced from those modules alone.
+* ``stpy.continuous_processes.gauss_procc`` and ``stpy.estimator`` import optional solver packages
+  at module top (cvxpy, cvxpylayers, pymanopt, torchmin, autograd_minimize, mosek) that are not
+  installed here and that the squared-loss path (fit_gp / mean_std / execute / log_marginal) never
+  calls.  ``sys.modules`` is pre-seeded with inert placeholders for those names so the module body
+  can execute; every number stored below is computed by the reference's own code
+  (torch.linalg.lstsq / lu / slogdet / solve on CPU).
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+for name in ["cvxpy", "cvxpylayers", "cvxpylayers.torch", "pymanopt", "pymanopt.manifolds",
+			 "pymanopt.optimizers", "pymanopt.function", "torchmin", "autograd_minimize", "mosek"]:
+	if name not in sys.modules:
+		sys.modules[name] = mock.MagicMock()
+
+from stpy.kernels import KernelFunction                                   # noqa: E402
+from stpy.embeddings.embedding import RFFEmbedding                        # noqa: E402
+from stpy.continuous_processes.gauss_procc import GaussianProcess         # noqa: E402
+from stpy.estimator import Estimator                                      # noqa: E402
+import stpy.helpers.helper as helper                                      # noqa: E402
+
+
+def simple_1d(X):
+	# synthetic target of BASELINE config 1 (formula of test_functions/benchmarks.py:478-482; that module
+	# needs h5py to import, and y is an *input* of the fixtures, so the formula is evaluated here)
+	z = (X + 0.5) * 1.2
+	return -(1.4 - 3 * z) * np.sin(18 * z)
+
+
+def T(a):
+	return torch.from_numpy(np.ascontiguousarray(a)).double()
+
+
+def N(t):
+	return t.detach().numpy().copy()
+
+
+def save(name, **arrays):
+	path = os.path.join(HERE, name + ".npz")
+	np.savez_compressed(path, **arrays)
+	print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def gp_outputs(GP, xtest, n_head=16):
+	mu, std = GP.mean_std(xtest)
+	K = GP.get_kernel()
+	return dict(mu=N(mu), std=N(std), K_head=N(K[:8, :8]), K_trace=np.array(float(torch.trace(K))),
+				K_fro=np.array(float(torch.norm(K))), A_head=N(GP.A[:n_head]), A_norm=np.array(float(torch.norm(GP.A))))
+
+
+def lml(GP, X=None, weight=1.0):
+	return N(GP.log_marginal(GP.kernel_object, {} if X is None else X, weight))
+
+
+def main():
+	rng = np.random.RandomState(20241101)
+
+	# ---------------------------------------------------------------- K1: bare kernel matrices
+	a = rng.uniform(-1, 1, size=(5, 3))
+	b = rng.uniform(-1, 1, size=(7, 3))
+	out = {}
+	out["se"] = N(KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3).kernel(T(a), T(b)))
+	out["se_group"] = N(KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3, group=[0, 2]).kernel(T(a), T(b)))
+	out["ard"] = N(KernelFunction(kernel_name="ard", ard_gamma=torch.tensor([0.5, 1.0, 2.0], dtype=torch.float64), kappa=0.9, d=3).kernel(T(a), T(b)))
+	for nu in (0.5, 1.5, 2.5):
+		out["matern_%s" % str(nu).replace(".", "")] = N(KernelFunction(kernel_name="matern", gamma=1.7, nu=nu, kappa=1.1, d=3).kernel(T(a), T(b)))
+		out["ard_matern_%s" % str(nu).replace(".", "")] = N(KernelFunction(kernel_name="ard_matern", ard_gamma=torch.tensor([0.5, 1.0, 2.0], dtype=torch.float64), nu=nu, kappa=1.1, d=3).kernel(T(a), T(b)))
+	out["linear"] = N(KernelFunction(kernel_name="linear", kappa=2.0, d=3, offset=0.25).kernel(T(a), T(b)))
+	k1 = KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3)
+	k2 = KernelFunction(kernel_name="matern", gamma=1.7, nu=2.5, kappa=0.5, d=3)
+	out["sum"] = N((k1 + k2).kernel(T(a), T(b)))
+	k1 = KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3)
+	k2 = KernelFunction(kernel_name="ard", ard_gamma=torch.tensor([0.5, 1.0, 2.0], dtype=torch.float64), kappa=0.9, d=3)
+	out["prod"] = N((k1 * k2).kernel(T(a), T(b)))
+	# kwargs override protocol (kernels.py:138-157)
+	kse = KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3)
+	for i, g in enumerate((0.3, 1.0, 2.5)):
+		out["se_override_%d" % i] = N(kse.kernel(T(a), T(b), **{'0': {'gamma': torch.tensor(g, dtype=torch.float64)}}))
+	out["se_override_gammas"] = np.array([0.3, 1.0, 2.5])
+	# self-kernel symmetry / diagonal
+	x8 = rng.uniform(-1, 1, size=(9, 3))
+	out["se_self"] = N(KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3).kernel(T(x8), T(x8)))
+	save("K1_kernels", a=a, b=b, x8=x8, **out)
+
+	# ---------------------------------------------------------------- G1: config-1 shaped (tutorial values)
+	Ntr, M = 512, 256
+	x = rng.uniform(-0.5, 0.0, size=(Ntr, 1))
+	y = simple_1d(x) + 0.01 * rng.normal(size=(Ntr, 1))
+	xtest = helper.interval(M, 1, L_infinity_ball=0.5)
+	for tag, s in (("G1_c1_s001", 0.01), ("G1_c1_s01", 0.1)):
+		GP = GaussianProcess(gamma=0.1, s=s, kappa=1.0, kernel_name="squared_exponential", d=1)
+		GP.fit_gp(T(x), T(y))
+		o = gp_outputs(GP, T(xtest))
+		save(tag, x=x, y=y, xtest=xtest, gamma=np.array(0.1), s=np.array(s), kappa=np.array(1.0),
+			 lml=lml(GP), lml_w05=lml(GP, weight=0.5), **o)
+
+	# ---------------------------------------------------------------- G2: d=8 SE, kappa != 1, and a column group
+	Ntr, M, d = 256, 64, 8
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(x.sum(axis=1, keepdims=True)) + 0.1 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	GP = GaussianProcess(gamma=1.0, s=0.1, kappa=1.7, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(T(x), T(y))
+	o = gp_outputs(GP, T(xtest))
+	kg = KernelFunction(kernel_name="squared_exponential", gamma=1.0, kappa=1.7, d=d, group=[0, 2, 5])
+	GPg = GaussianProcess(s=0.1, kernel=kg)
+	GPg.fit_gp(T(x), T(y))
+	og = gp_outputs(GPg, T(xtest))
+	save("G2_se_d8", x=x, y=y, xtest=xtest, gamma=np.array(1.0), s=np.array(0.1), kappa=np.array(1.7),
+		 lml=lml(GP), group=np.array([0, 2, 5]), lml_group=lml(GPg),
+		 **o, **{"group_" + k: v for k, v in og.items()})
+
+	# ---------------------------------------------------------------- G3: Matern nu in {1/2, 3/2, 5/2}, d=16
+	Ntr, M, d = 256, 64, 16
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(x.sum(axis=1, keepdims=True)) + 0.1 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	out = {}
+	for nu in (0.5, 1.5, 2.5):
+		GP = GaussianProcess(gamma=2.0, s=0.1, kappa=1.0, kernel_name="matern", nu=nu, d=d)
+		GP.fit_gp(T(x), T(y))
+		tag = "nu%s_" % str(nu).replace(".", "")
+		out.update({tag + k: v for k, v in gp_outputs(GP, T(xtest)).items()})
+		out[tag + "lml"] = lml(GP)
+	save("G3_matern_d16", x=x, y=y, xtest=xtest, gamma=np.array(2.0), s=np.array(0.1), kappa=np.array(1.0), **out)
+
+	# ---------------------------------------------------------------- G4: ARD and ARD-Matern, d=4
+	Ntr, M, d = 200, 50, 4
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.cos(x @ np.array([[1.0], [0.5], [2.0], [0.1]])) + 0.05 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	ag = np.array([0.5, 1.0, 2.0, 4.0])
+	out = {}
+	kk = KernelFunction(kernel_name="ard", ard_gamma=T(ag), kappa=1.2, d=d)
+	GP = GaussianProcess(s=0.2, kernel=kk)
+	GP.fit_gp(T(x), T(y))
+	out.update({"ard_" + k: v for k, v in gp_outputs(GP, T(xtest)).items()})
+	out["ard_lml"] = lml(GP)
+	out["ard_lml_override"] = lml(GP, {'0': {'ard_gamma': T(ag * 1.5)}})
+	for nu in (1.5, 2.5):
+		kk = KernelFunction(kernel_name="ard_matern", ard_gamma=T(ag), nu=nu, kappa=1.2, d=d)
+		GP = GaussianProcess(s=0.2, kernel=kk)
+		GP.fit_gp(T(x), T(y))
+		tag = "ardm%s_" % str(nu).replace(".", "")
+		out.update({tag + k: v for k, v in gp_outputs(GP, T(xtest)).items()})
+		out[tag + "lml"] = lml(GP)
+	save("G4_ard_d4", x=x, y=y, xtest=xtest, ard_gamma=ag, s=np.array(0.2), kappa=np.array(1.2), **out)
+
+	# ---------------------------------------------------------------- G5: composite kernels through the GP
+	Ntr, M, d = 128, 32, 3
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(2 * x[:, :1]) + x[:, 1:2] * x[:, 2:3] + 0.1 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	out = {}
+	k1 = KernelFunction(kernel_name="squared_exponential", gamma=0.8, kappa=1.0, d=d)
+	k2 = KernelFunction(kernel_name="matern", gamma=1.5, nu=2.5, kappa=0.5, d=d)
+	GP = GaussianProcess(s=0.1, kernel=k1 + k2)
+	GP.fit_gp(T(x), T(y))
+	out.update({"sum_" + k: v for k, v in gp_outputs(GP, T(xtest)).items()})
+	out["sum_lml"] = lml(GP)
+	k1 = KernelFunction(kernel_name="squared_exponential", gamma=0.8, kappa=1.0, d=d)
+	k2 = KernelFunction(kernel_name="squared_exponential", gamma=2.0, kappa=0.7, d=d, group=[1, 2])
+	GP = GaussianProcess(s=0.1, kernel=k1 * k2)
+	GP.fit_gp(T(x), T(y))
+	out.update({"prod_" + k: v for k, v in gp_outputs(GP, T(xtest)).items()})
+	out["prod_lml"] = lml(GP)
+	save("G5_composite", x=x, y=y, xtest=xtest, s=np.array(0.1), **out)
+
+	# ---------------------------------------------------------------- G6: kwargs override + log_marginal(kernel, X, weight)
+	Ntr, d = 192, 2
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(3 * x[:, :1]) * np.cos(2 * x[:, 1:2]) + 0.1 * rng.normal(size=(Ntr, 1))
+	GP = GaussianProcess(gamma=0.5, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(T(x), T(y))
+	gam = np.array([0.2, 0.5, 1.3])
+	lmls = np.zeros((3, 2))
+	for i, g in enumerate(gam):
+		for j, w in enumerate((1.0, 0.5)):
+			lmls[i, j] = float(GP.log_marginal(GP.kernel_object, {'0': {'gamma': torch.tensor(g, dtype=torch.float64)}}, w))
+	# Estimator.log_marginal (explicit Cholesky, estimator.py:32-40) on the same object
+	lml_est = N(Estimator.log_marginal(GP, GP.kernel_object, {}, 1.0))
+	save("G6_override_lml", x=x, y=y, gamma=np.array(0.5), s=np.array(0.1), gammas=gam, weights=np.array([1.0, 0.5]),
+		 lmls=lmls, lml_default=lml(GP), lml_estimator=lml_est)
+
+	# ---------------------------------------------------------------- G7: full=True covariance, prior branch, execute
+	Ntr, M, d = 96, 32, 2
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(3 * x[:, :1]) + 0.1 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	GP = GaussianProcess(gamma=0.6, s=0.1, kappa=1.4, kernel_name="squared_exponential", d=d)
+	# unfitted prior branch: full=False raises TypeError in this snapshot (gauss_procc.py:346 evaluates
+	# kernel(self.x=None, xtest) before the fitted check); only full=True reaches :349-363
+	try:
+		GP.mean_std(T(xtest))
+		prior_full_false_raises = 0
+	except TypeError:
+		prior_full_false_raises = 1
+	mu0f, cov0f = GP.mean_std(T(xtest), full=True)
+	ks0, kss0 = GP.execute(T(xtest))
+	assert ks0 is None
+	GP.fit_gp(T(x), T(y))
+	muf, cov = GP.mean_std(T(xtest), full=True)
+	ks, kss = GP.execute(T(xtest))
+	mean_only = GP.mean(T(xtest))
+	save("G7_full_prior", x=x, y=y, xtest=xtest, gamma=np.array(0.6), s=np.array(0.1), kappa=np.array(1.4),
+		 prior_full_false_raises=np.array(prior_full_false_raises), prior_full_mu=N(mu0f), prior_full_cov=N(cov0f), prior_kss=N(kss0),
+		 full_mu=N(muf), full_cov=N(cov), exec_ks=N(ks), exec_kss=N(kss), mean=N(mean_only),
+		 ucb=N(GP.ucb(T(xtest))), lcb=N(GP.lcb(T(xtest))))
+
+	# ---------------------------------------------------------------- G8: chunked prediction (max_size patched to 64, M=200)
+	Ntr, M, d = 128, 200, 2
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(3 * x[:, :1]) + 0.1 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	GP = GaussianProcess(gamma=0.6, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(T(x), T(y))
+	GP.max_size = 64
+	mu, std = GP.mean_std(T(xtest))
+	save("G8_chunked", x=x, y=y, xtest=xtest, gamma=np.array(0.6), s=np.array(0.1), max_size=np.array(64), mu=N(mu), std=N(std))
+
+	# ---------------------------------------------------------------- G9: add_data_point x3 then mean_std
+	d = 2
+	xs = [rng.uniform(-1, 1, size=(n, d)) for n in (40, 1, 7)]
+	ys = [np.sin(3 * xx[:, :1]) + 0.1 * rng.normal(size=(xx.shape[0], 1)) for xx in xs]
+	xtest = rng.uniform(-1, 1, size=(33, d))
+	GP = GaussianProcess(gamma=0.6, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	for xx, yy in zip(xs, ys):
+		GP.add_data_point(T(xx), T(yy))
+	o = gp_outputs(GP, T(xtest))
+	save("G9_add_data_point", x0=xs[0], x1=xs[1], x2=xs[2], y0=ys[0], y1=ys[1], y2=ys[2], xtest=xtest,
+		 gamma=np.array(0.6), s=np.array(0.1), n=np.array(GP.n), **o)
+
+	# ---------------------------------------------------------------- G10: RFF embed
+	m, d, n = 64, 5, 33
+	W = rng.normal(size=(m, d)) / 0.7
+	bvec = 2 * np.pi * rng.uniform(size=(m,))
+	xr = rng.uniform(0, 1, size=(n, d))
+	emb = RFFEmbedding(gamma=0.7, m=m, d=d, kappa=1.0)
+	emb.W = T(W)
+	z = N(emb.embed(T(xr)))
+	emb2 = RFFEmbedding(gamma=0.7, m=m, d=d, kappa=2.5)
+	emb2.W = T(W)
+	z_k = N(emb2.embed(T(xr)))
+	embb = RFFEmbedding(gamma=0.7, m=m, d=d, kappa=2.5, biased=True)
+	embb.W = T(W)
+	embb.b = T(bvec)
+	z_b = N(embb.embed(T(xr)))
+	# x with fewer columns than d: embed uses W[:, 0:d_x]   (embedding.py:230,234)
+	z_sub = N(emb.embed(T(xr[:, :3])))
+	# sampler pin: np.random.seed(0) -> W = N(0,1)/gamma
+	np.random.seed(0)
+	embs = RFFEmbedding(gamma=0.7, m=8, d=3)
+	W_seed0 = N(embs.W)
+	np.random.seed(0)
+	embsb = RFFEmbedding(gamma=0.7, m=8, d=3, biased=True)
+	save("G10_rff", W=W, b=bvec, x=xr, gamma=np.array(0.7), m=np.array(m), z=z, z_kappa25=z_k, z_biased_kappa25=z_b,
+		 z_sub3=z_sub, W_seed0=W_seed0, W_seed0_biased=N(embsb.W), b_seed0_biased=N(embsb.b))
+
+	# ---------------------------------------------------------------- G11: back_prop=False (LU) branch equals default
+	Ntr, M, d = 128, 40, 3
+	x = rng.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(x.sum(axis=1, keepdims=True)) + 0.1 * rng.normal(size=(Ntr, 1))
+	xtest = rng.uniform(-1, 1, size=(M, d))
+	GP = GaussianProcess(gamma=1.0, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.back_prop = False
+	GP.fit_gp(T(x), T(y))
+	mu, std = GP.mean_std(T(xtest))
+	GP2 = GaussianProcess(gamma=1.0, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP2.fit_gp(T(x), T(y))
+	mu2, std2 = GP2.mean_std(T(xtest))
+	save("G11_lu_branch", x=x, y=y, xtest=xtest, gamma=np.array(1.0), s=np.array(0.1), mu_lu=N(mu), std_lu=N(std),
+		 mu=N(mu2), std=N(std2))
+
+	# ---------------------------------------------------------------- H1: helpers
+	save("H1_helpers", interval_5_2=helper.interval(5, 2), interval_4_1_half=helper.interval(4, 1, L_infinity_ball=0.5),
+		 cartesian_2x3=helper.cartesian([np.array([1., 2.]), np.array([3., 4., 5.])]))
+
+
+if __name__ == "__main__":
+	main()

@@ -1,0 +1,191 @@
+"""
+Pins the CPU oracle (oracle/gp_oracle.py) against the golden vectors captured from the real
+reference (tests/golden/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+from tests.conftest import golden, rel_err
+
+TOL = 1e-10          # oracle (Cholesky) vs reference (lstsq / LU / slogdet), fp64, well-conditioned cases
+TOL_ILL = 2e-6       # G1 tutorial case gamma=0.1, s=0.01 in 1-D: cond(K) ~ 1e7, both sides lose digits
+
+
+def se_spec(gamma, kappa=1.0, group=None):
+	return [("squared_exponential", {"gamma": float(gamma), "kappa": float(kappa), "group": group}, "-")]
+
+
+def check_gp(g, spec, s, prefix="", tol=TOL):
+	L, alpha = O.fit(g["x"], g["y"], spec, s)
+	mu, std = O.mean_std(g["x"], L, alpha, g["xtest"], spec)
+	K = O.gram_train(g["x"], spec, s)
+	assert rel_err(mu, g[prefix + "mu"]) < tol
+	assert rel_err(std, g[prefix + "std"]) < tol
+	assert rel_err(K[:8, :8], g[prefix + "K_head"]) < 1e-13
+	assert abs(np.trace(K) - g[prefix + "K_trace"]) / g[prefix + "K_trace"] < 1e-13
+	assert abs(np.linalg.norm(K) - g[prefix + "K_fro"]) / g[prefix + "K_fro"] < 1e-13
+	assert rel_err(alpha[:16], g[prefix + "A_head"]) < tol * 100
+	return L, alpha
+
+
+def test_K1_kernels():
+	g = golden("K1_kernels")
+	a, b = g["a"], g["b"]
+	assert g["se"].shape == (7, 5)
+	assert rel_err(O.squared_exponential(a, b, 0.7, 1.3), g["se"]) < 1e-14
+	assert rel_err(O.squared_exponential(a, b, 0.7, 1.3, group=[0, 2]), g["se_group"]) < 1e-14
+	assert rel_err(O.ard(a, b, [0.5, 1.0, 2.0], 0.9), g["ard"]) < 1e-14
+	for nu in (0.5, 1.5, 2.5):
+		tag = str(nu).replace(".", "")
+		assert rel_err(O.matern(a, b, 1.7, nu, 1.1), g["matern_" + tag]) < 1e-14
+		assert rel_err(O.ard_matern(a, b, [0.5, 1.0, 2.0], nu, 1.1), g["ard_matern_" + tag]) < 1e-14
+	assert rel_err(O.linear(a, b, 2.0, 0.25), g["linear"]) < 1e-15
+	spec = [("squared_exponential", {"gamma": 0.7, "kappa": 1.3}, "-"), ("matern", {"gamma": 1.7, "nu": 2.5, "kappa": 0.5}, "+")]
+	assert rel_err(O.kernel(a, b, spec), g["sum"]) < 1e-14
+	spec = [("squared_exponential", {"gamma": 0.7, "kappa": 1.3}, "-"), ("ard", {"ard_gamma": [0.5, 1.0, 2.0], "kappa": 0.9}, "*")]
+	assert rel_err(O.kernel(a, b, spec), g["prod"]) < 1e-14
+	for i, gam in enumerate(g["se_override_gammas"]):
+		k = O.kernel(a, b, se_spec(0.7, 1.3), overrides={'0': {'gamma': float(gam)}})
+		assert rel_err(k, g["se_override_%d" % i]) < 1e-14
+	ks = O.squared_exponential(g["x8"], g["x8"], 0.7, 1.3)
+	assert rel_err(ks, g["se_self"]) < 1e-14
+	assert np.allclose(np.diag(g["se_self"]), 1.3, rtol=0, atol=1e-14)        # K_ii = kappa
+	assert np.abs(g["se_self"] - g["se_self"].T).max() < 1e-15
+
+
+@pytest.mark.parametrize("name,tol", [("G1_c1_s001", TOL_ILL), ("G1_c1_s01", 1e-8)])
+def test_G1_config1(name, tol):
+	g = golden(name)
+	spec = se_spec(g["gamma"], g["kappa"])
+	check_gp(g, spec, float(g["s"]), tol=tol)
+	lm = O.log_marginal(g["x"], g["y"], spec, float(g["s"]))
+	assert lm.shape == (1, 1) and g["lml"].shape == (1, 1)
+	assert abs(lm - g["lml"]) / abs(g["lml"]) < tol
+	lm5 = O.log_marginal(g["x"], g["y"], spec, float(g["s"]), weight=0.5)
+	assert abs(lm5 - g["lml_w05"]) / abs(g["lml_w05"]) < tol
+
+
+def test_G2_se_d8():
+	g = golden("G2_se_d8")
+	s = float(g["s"])
+	spec = se_spec(g["gamma"], g["kappa"])
+	check_gp(g, spec, s)
+	assert abs(O.log_marginal(g["x"], g["y"], spec, s) - g["lml"]) / abs(g["lml"]) < TOL
+	specg = se_spec(g["gamma"], g["kappa"], group=[int(i) for i in g["group"]])
+	check_gp(g, specg, s, prefix="group_")
+	assert abs(O.log_marginal(g["x"], g["y"], specg, s) - g["lml_group"]) / abs(g["lml_group"]) < TOL
+
+
+def test_G3_matern():
+	g = golden("G3_matern_d16")
+	s = float(g["s"])
+	for nu in (0.5, 1.5, 2.5):
+		tag = "nu%s_" % str(nu).replace(".", "")
+		spec = [("matern", {"gamma": float(g["gamma"]), "nu": nu, "kappa": float(g["kappa"])}, "-")]
+		check_gp(g, spec, s, prefix=tag)
+		lm = O.log_marginal(g["x"], g["y"], spec, s)
+		assert abs(lm - g[tag + "lml"]) / abs(g[tag + "lml"]) < TOL
+
+
+def test_G4_ard():
+	g = golden("G4_ard_d4")
+	s = float(g["s"])
+	ag = g["ard_gamma"]
+	spec = [("ard", {"ard_gamma": ag, "kappa": float(g["kappa"])}, "-")]
+	check_gp(g, spec, s, prefix="ard_")
+	assert abs(O.log_marginal(g["x"], g["y"], spec, s) - g["ard_lml"]) / abs(g["ard_lml"]) < TOL
+	lmo = O.log_marginal(g["x"], g["y"], spec, s, overrides={'0': {'ard_gamma': ag * 1.5}})
+	assert abs(lmo - g["ard_lml_override"]) / abs(g["ard_lml_override"]) < TOL
+	for nu in (1.5, 2.5):
+		tag = "ardm%s_" % str(nu).replace(".", "")
+		spec = [("ard_matern", {"ard_gamma": ag, "nu": nu, "kappa": float(g["kappa"])}, "-")]
+		check_gp(g, spec, s, prefix=tag)
+		assert abs(O.log_marginal(g["x"], g["y"], spec, s) - g[tag + "lml"]) / abs(g[tag + "lml"]) < TOL
+
+
+def test_G5_composite():
+	g = golden("G5_composite")
+	s = float(g["s"])
+	spec = [("squared_exponential", {"gamma": 0.8, "kappa": 1.0}, "-"), ("matern", {"gamma": 1.5, "nu": 2.5, "kappa": 0.5}, "+")]
+	check_gp(g, spec, s, prefix="sum_")
+	assert abs(O.log_marginal(g["x"], g["y"], spec, s) - g["sum_lml"]) / abs(g["sum_lml"]) < TOL
+	spec = [("squared_exponential", {"gamma": 0.8, "kappa": 1.0}, "-"),
+			("squared_exponential", {"gamma": 2.0, "kappa": 0.7, "group": [1, 2]}, "*")]
+	check_gp(g, spec, s, prefix="prod_")
+	assert abs(O.log_marginal(g["x"], g["y"], spec, s) - g["prod_lml"]) / abs(g["prod_lml"]) < TOL
+
+
+def test_G6_override_lml():
+	g = golden("G6_override_lml")
+	s = float(g["s"])
+	spec = se_spec(g["gamma"])
+	for i, gam in enumerate(g["gammas"]):
+		for j, w in enumerate(g["weights"]):
+			lm = O.log_marginal(g["x"], g["y"], spec, s, overrides={'0': {'gamma': float(gam)}}, weight=float(w))
+			assert abs(lm - g["lmls"][i, j]) / abs(g["lmls"][i, j]) < 1e-9
+	assert abs(O.log_marginal(g["x"], g["y"], spec, s) - g["lml_default"]) / abs(g["lml_default"]) < TOL
+	# the reference's two formulations (slogdet+solve vs explicit Cholesky) agree with each other
+	assert abs(g["lml_default"] - g["lml_estimator"]) / abs(g["lml_default"]) < 1e-11
+
+
+def test_G7_full_prior_execute():
+	g = golden("G7_full_prior")
+	s = float(g["s"])
+	spec = se_spec(g["gamma"], g["kappa"])
+	assert int(g["prior_full_false_raises"]) == 1
+	assert np.all(g["prior_full_mu"] == 0)
+	assert rel_err(O.kernel(g["xtest"], g["xtest"], spec), g["prior_full_cov"]) < 1e-14
+	assert rel_err(O.kernel(g["xtest"], g["xtest"], spec), g["prior_kss"]) < 1e-14
+	L, alpha = O.fit(g["x"], g["y"], spec, s)
+	mu, cov = O.mean_cov(g["x"], L, alpha, g["xtest"], spec)
+	assert rel_err(mu, g["full_mu"]) < TOL
+	assert rel_err(cov, g["full_cov"]) < 1e-9
+	assert rel_err(O.kernel(g["x"], g["xtest"], spec), g["exec_ks"]) < 1e-14
+	assert g["exec_ks"].shape == (g["xtest"].shape[0], g["x"].shape[0])
+	assert rel_err(mu, g["mean"]) < TOL
+	mu2, std = O.mean_std(g["x"], L, alpha, g["xtest"], spec)
+	assert rel_err(mu2 + 2 * std, g["ucb"]) < TOL
+	assert rel_err(mu2 - 2 * std, g["lcb"]) < TOL
+
+
+def test_G8_chunked_and_G11_lu():
+	g = golden("G8_chunked")
+	spec = se_spec(g["gamma"])
+	L, alpha = O.fit(g["x"], g["y"], spec, float(g["s"]))
+	mu, std = O.mean_std(g["x"], L, alpha, g["xtest"], spec)
+	assert rel_err(mu, g["mu"]) < TOL and rel_err(std, g["std"]) < TOL
+	g = golden("G11_lu_branch")
+	spec = se_spec(g["gamma"])
+	L, alpha = O.fit(g["x"], g["y"], spec, float(g["s"]))
+	mu, std = O.mean_std(g["x"], L, alpha, g["xtest"], spec)
+	assert rel_err(mu, g["mu"]) < TOL and rel_err(std, g["std"]) < TOL
+	assert rel_err(mu, g["mu_lu"]) < TOL and rel_err(std, g["std_lu"]) < TOL
+
+
+def test_G9_add_data_point():
+	g = golden("G9_add_data_point")
+	x = np.concatenate([g["x0"], g["x1"], g["x2"]])
+	y = np.concatenate([g["y0"], g["y1"], g["y2"]])
+	assert int(g["n"]) == x.shape[0]
+	gg = dict(g, x=x, y=y)
+	check_gp(gg, se_spec(g["gamma"]), float(g["s"]))
+
+
+def test_G10_rff():
+	g = golden("G10_rff")
+	m = int(g["m"])
+	assert rel_err(O.rff_embed(g["x"], g["W"], m), g["z"]) < 1e-15
+	assert rel_err(O.rff_embed(g["x"], g["W"], m, kappa=2.5), g["z_kappa25"]) < 1e-15
+	assert rel_err(O.rff_embed(g["x"], g["W"], m, kappa=2.5, b=g["b"]), g["z_biased_kappa25"]) < 1e-15
+	assert rel_err(O.rff_embed(g["x"][:, :3], g["W"], m), g["z_sub3"]) < 1e-15
+	assert g["z"].shape == (g["x"].shape[0], m)
+	assert g["z_biased_kappa25"].shape == (m, g["x"].shape[0])     # reference quirk: biased branch is (m, n)
+	assert rel_err(O.rff_sample_W(0.7, 8, 3, rng_state=0), g["W_seed0"]) < 1e-15
+	assert rel_err(O.rff_sample_W(0.7, 8, 3, rng_state=0), g["W_seed0_biased"]) < 1e-15
+
+
+def test_H1_helpers():
+	g = golden("H1_helpers")
+	assert np.array_equal(O.interval(5, 2), g["interval_5_2"])
+	assert np.array_equal(O.interval(4, 1, 0.5), g["interval_4_1_half"])
