@@ -1,0 +1,130 @@
+/*
+ * stpy_hip.h -- C ABI of libstpy_hip.so: the MI355X (gfx950) implementation of the dense
+ * linear-algebra hot path of Mojusko/stpy (kernel Gram matrices, blocked Cholesky, triangular
+ * solves, GP prediction epilogue, log-marginal reductions, random-Fourier-feature embed).
+ *
+ * The reference has no FFI of its own: the path sits behind Python methods that call torch CPU
+ * ops.  Each entry point below replaces the torch/scipy call sequence cited next to it
+ * (file:line relative to the reference root); INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer into caller-owned memory (PyTorch-ROCm storage in the
+ *     shipped host code); matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *   - dtype: 0 = float64, 1 = float32 (all operands of one call share it);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - no allocation, no ownership transfer, no global mutable state besides a thread-local
+ *     last-error string; workspaces are sized by the *_workspace_bytes queries;
+ *   - return value: 0 = ok, <0 = invalid argument (-(index of the argument), 1-based) or
+ *     -1000-hipError for a failed launch; numerical failure of the factorisation is reported
+ *     through the device word `info_dev` (0 = ok, j>0 = leading minor j not positive definite),
+ *     exactly LAPACK's potrf convention, so the host decides when to synchronise and read it.
+ */
+#ifndef STPY_HIP_H
+#define STPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { STPY_F64 = 0, STPY_F32 = 1 };
+
+/* stationary / dot-product kernel families; lengthscales arrive as inv_ls[k] = 1/ell_k */
+enum {
+	STPY_K_SE = 0,        /* kappa * exp(-r^2/2)                      kernels.py:368-398, :552-583 (ard) */
+	STPY_K_MATERN12 = 1,  /* kappa * exp(-r)                          kernels.py:844-845                 */
+	STPY_K_MATERN32 = 2,  /* kappa * (1+sqrt3 r) exp(-sqrt3 r)        kernels.py:846-848                 */
+	STPY_K_MATERN52 = 3,  /* kappa * (1+sqrt5 r+5r^2/3) exp(-sqrt5 r) kernels.py:849-851, :946-962       */
+	STPY_K_LINEAR = 4     /* kappa * <b_j, a_i> + offset              kernels.py:300-320                 */
+};
+
+/* how a kernel evaluation is combined into `out` -- the + and * kernel algebra of kernels.py:146-157 */
+enum { STPY_OUT_SET = 0, STPY_OUT_ADD = 1, STPY_OUT_MUL = 2 };
+
+const char* stpy_version(void);
+const char* stpy_last_error_string(void);
+
+/*
+ * Gram matrix, replaces KernelFunction.kernel(a, b) for one kernel item (kernels.py:136-159):
+ *   out[j*ldo + i] (op)= kappa * phi(|| (b_j - a_i)[cols] * inv_ls ||) (+ offset for LINEAR)
+ *                        + diag_add * [i == j]
+ * a: n x lda, b: q x ldb, out: q x n  (orientation (|b|,|a|) as kernels.py:393).
+ * cols: device int32[d] column subset ("group", kernels.py:387-388) or NULL for 0..d-1.
+ * inv_ls: device array of d elements of `dtype`.  lower_only != 0 writes only i <= j blocks
+ * (used when a == b feeds the Cholesky).  diag_add carries s^2 of gauss_procc.py:151-163.
+ */
+int stpy_gram(int kind, int dtype,
+              const void* a, int64_t n, int64_t lda,
+              const void* b, int64_t q, int64_t ldb,
+              int d, const int32_t* cols, const void* inv_ls,
+              double kappa, double offset, double diag_add,
+              int lower_only, int combine,
+              void* out, int64_t ldo, void* stream);
+
+/* k(x_i, x_i) for i < m -- replaces the per-point Python loop of gauss_procc.py:347 */
+int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,
+                   int d, const int32_t* cols, const void* inv_ls,
+                   double kappa, double offset, int combine, void* out, void* stream);
+
+/*
+ * Blocked right-looking Cholesky, A = L L^T in place in the lower triangle (the strict upper
+ * triangle is scratch).  Replaces torch.linalg.cholesky (estimator.py:35) and stands in for
+ * lstsq / lu_factor / slogdet (gauss_procc.py:370-378, :634).
+ * winv: ceil(n/128) blocks of 128x128 elements; receives inverse(L_cc) of every 128x128
+ *       diagonal block (reused by the triangular solves below).
+ * work: stpy_potrf_workspace_bytes(dtype, n, nb) bytes.   nb: outer panel width, multiple of 128
+ *       (0 = library default).   info_dev: device int32.
+ */
+int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb);
+int64_t stpy_potrf_winv_elems(int64_t n);
+int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int nb,
+               int32_t* info_dev, void* stream);
+
+/* B <- B L^-T for B: m x n row-major (rows = right-hand sides).  With B = K* (M x N) this is
+ * V^T = (L^-1 K*^T)^T of the variance term, gauss_procc.py:378,392. */
+int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
+                       const void* winv, void* B, int64_t ldb, int nb, void* stream);
+
+/* out = L^-1 y (trans = 0) or out = L^-T y (trans = 1); the two together are cholesky_solve,
+ * estimator.py:37.  y is used as scratch (destroyed); out must not alias y. */
+int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* y,
+              void* out, int trans, void* stream);
+
+/* mu[i] = <X_i, z>,  sigma[i] = sqrt(kdiag[i] - <X_i, X_i>)   (X = K* L^-T, z = L^-1 y)
+ * gauss_procc.py:381, :391-395.  clamp != 0 clamps the variance at 0 before the sqrt (the
+ * reference does not clamp).  mu or sigma may be NULL. */
+int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, const void* z,
+                 const void* kdiag, void* mu, void* sigma, int clamp, void* stream);
+
+/* out2[0] = sum_i log L_ii,  out2[1] = z^T z   (estimator.py:36-38, gauss_procc.py:634-636) */
+int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const void* z,
+                     void* out2, void* stream);
+
+/* C (op) A B^T with A: m x k, B: n x k, C: m x n.  mode 0: C = A B^T, 1: C -= A B^T.
+ * lower_only: skip 128x128 tiles strictly above the diagonal (m == n).  This is the MFMA
+ * contraction under potrf / trsm; exported for the roofline bench and the full-covariance
+ * branch gauss_procc.py:396-399. */
+int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k,
+                 const void* A, int64_t lda, const void* B, int64_t ldb,
+                 void* C, int64_t ldc, int mode, int lower_only, void* stream);
+
+/* mirror the lower triangle into the upper one (n x n) -- materialises .K after a lower-only Gram */
+int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stream);
+
+/*
+ * Random Fourier features, replaces RFFEmbedding.embed (embedding.py:225-241):
+ *   bias == NULL: out[i*ldo + j] = scale * cos(<W_j, x_i>)  for j <  m/2
+ *                                  scale * sin(<W_j, x_i>)  for j >= m/2
+ *   bias != NULL: out[i*ldo + j] = scale * cos(<W_j, x_i> + bias[j])
+ * x: n x ldx (d columns used), W: m x ldw, out: n x m;  scale = sqrt(2/m) * sqrt(kappa).
+ */
+int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
+                   const void* W, int64_t ldw, int64_t m, const void* bias, double scale,
+                   void* out, int64_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,336 @@
+"""
+Drop-in for ``stpy.continuous_processes.gauss_procc.GaussianProcess`` on the squared-loss path
+(reference: stpy/continuous_processes/gauss_procc.py:18-71 ctor, :100-117 add_data_point / fit,
+:136-177 fit_gp, :198-209 execute, :310-418 mean_std / mean, :497-504 + :631-638 log_marginal,
+:915 get_kernel; explicit-Cholesky form of the evidence in stpy/estimator.py:32-40).
+
+What runs where
+  Gram matrices      stpy_gram              (csrc/gram.hip)
+  K = L L^T          stpy_potrf             (csrc/potrf.hip + csrc/gemm.hip, fp64/fp32 MFMA)
+  z = L^-1 y, alpha  stpy_trsv              (csrc/solve.hip)
+  X = K* L^-T        stpy_trsm_right_lt     (csrc/solve.hip + csrc/gemm.hip)
+  mu, sigma          stpy_predict           (csrc/solve.hip)
+  log det, y^T K^-1 y  stpy_logdet_quad     (csrc/solve.hip)
+Python only sequences those calls and owns the torch tensors they operate on.
+
+The reference solves with lstsq / LU / slogdet; an SPD solve through the Cholesky factor is the
+same mathematics (and what Estimator.log_marginal does), agreement is checked to <= 1e-8 relative
+against golden vectors captured from the reference (tests/golden).
+
+Differences a caller can observe, all deliberate:
+  * ``self.K`` / ``self.Sigma`` are materialised lazily (the factorisation is in place; at
+    N = 65 536 a second N x N matrix is 34 GB); ``self.B`` (N x N, a by-product of the reference's
+    lstsq, gauss_procc.py:378) is not kept.
+  * prediction before ``fit`` with ``full=False`` returns the prior (0, sqrt(diag K**)) that
+    gauss_procc.py:349-363 intends; the reference snapshot raises TypeError there (:346).
+  * ``add_data`` / ``mean_var`` are aliases of ``add_data_point`` / ``mean_std`` (the names used in
+    BASELINE.json); like every ``mean_var`` in stpy they return (mean, *std*).
+  * robust losses, sampling helpers, gradients, UCB optimisation are outside the hot path.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..kernels import KernelFunction
+
+
+class GaussianProcess:
+
+	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", diameter=1.0,
+				 groups=None, bounds=None, nu=1.5, kernel=None, d=1, power=2, lam=1., loss='squared', huber_delta=1.35,
+				 hyper='classical', B=1., svr_eps=0.1):
+		if loss != 'squared':
+			raise NotImplementedError("loss='%s': only the squared loss is on the stpy_amd hot path "
+									  "(huber/svr/unif need cvxpy/MOSEK, gauss_procc.py:211-308)" % loss)
+		self.s = s
+		self.d = d
+		self.x = None
+		self.y = None
+		self.n = 0
+		self.mu = 0.0
+		self.lam = lam
+		self.total_bound = B
+		self.safe = False
+		self.fitted = False
+		self.diameter = diameter
+		self.bounds = bounds
+		self.admits_first_order = False
+		self.back_prop = True
+		self.loss = loss
+		self.hyper = hyper
+		self.max_size = 10000               # gauss_procc.py:55: prediction chunk
+		self.clamp_variance = False         # the reference takes sqrt of the raw difference (:394-395)
+		self.nb = 0                         # outer panel width for potrf/trsm (0 = library default)
+		if kernel is not None:
+			self.kernel_object = kernel
+			self.kernel = kernel.kernel
+			self.d = kernel.d
+		else:
+			self.kernel_object = KernelFunction(kernel_name=kernel_name, gamma=gamma, nu=nu, groups=groups, kappa=kappa,
+												power=power, d=d)
+			self.kernel = self.kernel_object.kernel
+			self.gamma = gamma
+			self.v = nu
+			self.groups = groups
+			self.kappa = kappa
+			self.custom = kernel
+			self.optkernel = kernel_name
+		# device state
+		self._xd = None
+		self._yd = None
+		self._L = None          # N x N, lower triangle = Cholesky factor of k(x,x) + Sigma^T Sigma
+		self._winv = None       # inverse 128 x 128 diagonal blocks of L
+		self._z = None          # L^-1 y
+		self._Sigma = None
+		self.A = None           # K^-1 y  (gauss_procc.py:376), (N, 1)
+
+	# ------------------------------------------------------------------ small API mirrors
+	def description(self):
+		return self.kernel_object.description() + "\nlambda=" + str(self.s)
+
+	def embed(self, x):
+		return self.kernel_object.embed(x)
+
+	def get_basis_size(self):
+		return self.kernel_object.get_basis_size()
+
+	def residuals(self, x, y):
+		return self.mean(x) - y
+
+	def add_data_point(self, x, y, Sigma=None):
+		"""gauss_procc.py:100-111: concatenate and refit from scratch."""
+		if self.x is not None:
+			self.x = torch.cat((self.x, x), dim=0)
+			self.y = torch.cat((self.y, y), dim=0)
+			if Sigma is None and self._Sigma is not None:
+				self._Sigma = torch.block_diag(self._Sigma, torch.eye(x.size()[0], dtype=torch.double) * self.s)
+		else:
+			self.x = x
+			self.y = y
+			self._Sigma = Sigma
+		self.fit_gp(self.x, self.y, Sigma=self._Sigma)
+
+	add_data = add_data_point
+
+	def fit(self, x=None, y=None):
+		"""gauss_procc.py:113-117."""
+		if x is not None:
+			self.fit_gp(x, y)
+		else:
+			self.fit_gp(self.x, self.y)
+
+	def lcb(self, xtest):
+		mu, s = self.mean_std(xtest)
+		return mu - 2 * s
+
+	def ucb(self, xtest):
+		mu, s = self.mean_std(xtest)
+		return mu + 2 * s
+
+	# ------------------------------------------------------------------ factorisation
+	def _factor(self, xd, kwargs=None, Sigma=None):
+		"""K_theta = k(x,x) + s^2 I (or + Sigma^T Sigma) -> in-place Cholesky.  Returns (L, winv)."""
+		lib = _lib.load()
+		n = xd.shape[0]
+		dt = _lib.dtype_code(xd.dtype)
+		K = torch.empty((n, n), dtype=xd.dtype, device=xd.device)
+		if Sigma is None:
+			self.kernel_object._kernel_into(xd, xd, K, kwargs, diag_add=float(self.s) ** 2, lower_only=True)
+		else:
+			# general noise matrix: off the hot path, one device matmul (gauss_procc.py:163)
+			self.kernel_object._kernel_into(xd, xd, K, kwargs)
+			Sd = _lib.to_device(Sigma, xd.dtype)
+			K.add_(Sd.T @ Sd)
+		winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=xd.dtype, device=xd.device)
+		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, n, self.nb)),), dtype=torch.uint8, device=xd.device)
+		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
+		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), _lib.ptr(work), self.nb, _lib.ptr(info), _lib.stream_ptr())
+		_lib.check(rc, "stpy_potrf")
+		bad = int(info.item())          # the one synchronisation of a fit
+		del work
+		if bad != 0:
+			raise torch.linalg.LinAlgError("stpy_potrf: the leading minor of order %d of K + s^2 I is not positive definite" % bad)
+		return K, winv
+
+	def _solve_y(self, L, winv, yd):
+		"""z = L^-1 y, alpha = L^-T z."""
+		lib = _lib.load()
+		n = L.shape[0]
+		dt = _lib.dtype_code(L.dtype)
+		scratch = yd.reshape(-1).clone()
+		z = torch.empty_like(scratch)
+		_lib.check(lib.stpy_trsv(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(z), 0, _lib.stream_ptr()), "stpy_trsv")
+		scratch.copy_(z)
+		alpha = torch.empty_like(scratch)
+		_lib.check(lib.stpy_trsv(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(alpha), 1, _lib.stream_ptr()), "stpy_trsv")
+		return z, alpha
+
+	def fit_gp(self, x, y, Sigma=None, iterative=False, extrapoint=False):
+		"""gauss_procc.py:136-177 (the ``iterative`` branch of the reference is a stub and is ignored)."""
+		try:
+			self.n, self.d = list(x.size())
+		except Exception:
+			self.n, self.d = x.shape
+		self.x = x
+		self.y = y
+		self._Sigma = Sigma
+		self._xd = _lib.to_device(x)
+		self._yd = _lib.to_device(y, self._xd.dtype).reshape(-1, 1)
+		self._L = self._winv = self._z = None       # release the previous factor before allocating the next
+		self._L, self._winv = self._factor(self._xd, None, Sigma)
+		self._z, alpha = self._solve_y(self._L, self._winv, self._yd)
+		self.A = _lib.like_input(alpha.reshape(-1, 1), x)
+		self._alpha = alpha
+		self.fitted = True
+		return None
+
+	# ------------------------------------------------------------------ lazily materialised reference attributes
+	@property
+	def K(self):
+		"""k(x,x) + Sigma^T Sigma (gauss_procc.py:163), recomputed on demand."""
+		if not self.fitted:
+			return np.array([1.0])              # gauss_procc.py:38
+		xd = self._xd
+		K = torch.empty((self.n, self.n), dtype=xd.dtype, device=xd.device)
+		if self._Sigma is None:
+			self.kernel_object._kernel_into(xd, xd, K, None, diag_add=float(self.s) ** 2)
+		else:
+			self.kernel_object._kernel_into(xd, xd, K, None)
+			Sd = _lib.to_device(self._Sigma, xd.dtype)
+			K.add_(Sd.T @ Sd)
+		return _lib.like_input(K, self.x)
+
+	@property
+	def Sigma(self):
+		if self._Sigma is not None:
+			return self._Sigma
+		return self.s * torch.eye(self.n, dtype=torch.float64)
+
+	def get_kernel(self):
+		return self.K
+
+	def norm(self):
+		"""gauss_procc.py:179-184: sqrt(alpha^T k(x,x) alpha)."""
+		if not self.fitted:
+			return None
+		Kxx = self.kernel_object.kernel(self._xd, self._xd)
+		return _lib.like_input(torch.sqrt(self._alpha.reshape(1, -1) @ Kxx @ self._alpha.reshape(-1, 1)), self.x)
+
+	# ------------------------------------------------------------------ prediction
+	def execute(self, xtest):
+		"""gauss_procc.py:198-209: (K* or None, K**)."""
+		K_star = self.kernel(self._xd, _lib.to_device(xtest, self._xd.dtype)) if self.fitted else None
+		if K_star is not None:
+			K_star = _lib.like_input(K_star, xtest)
+		K_star_star = self.kernel(xtest, xtest)
+		return (K_star, K_star_star)
+
+	def mean_std(self, xtest, full=False, reuse=False):
+		"""gauss_procc.py:310-334: chunks of ``max_size`` test points against the resident factor."""
+		m = xtest.size()[0]
+		if m < self.max_size or full:
+			return self.mean_std_sub(xtest, full=full, reuse=reuse)
+		dtype = self._xd.dtype if self.fitted else (xtest.dtype if xtest.dtype in (torch.float32, torch.float64) else torch.float64)
+		mu = torch.zeros(size=(m, 1), dtype=dtype, device=xtest.device)
+		std = torch.zeros(size=(m, 1), dtype=dtype, device=xtest.device)
+		for i0 in range(0, m, self.max_size):
+			mu[i0:i0 + self.max_size], std[i0:i0 + self.max_size] = self.mean_std_sub(xtest[i0:i0 + self.max_size, :], reuse=True)
+		return mu, std
+
+	mean_var = mean_std
+
+	def mean_std_sub(self, xtest, full=False, reuse=False):
+		"""gauss_procc.py:336-401 (squared loss)."""
+		lib = _lib.load()
+		ko = self.kernel_object
+		if not self.fitted:
+			xt = _lib.to_device(xtest)
+			if full:
+				cov = torch.empty((xt.shape[0], xt.shape[0]), dtype=xt.dtype, device=xt.device)
+				ko._kernel_into(xt, xt, cov)
+				yvar = cov
+			else:
+				kd = torch.empty((xt.shape[0],), dtype=xt.dtype, device=xt.device)
+				ko._diag_into(xt, kd)
+				yvar = torch.sqrt(kd).reshape(-1, 1)
+			zero = torch.zeros((xt.shape[0], 1), dtype=xt.dtype, device=xt.device)
+			return (_lib.like_input(zero, xtest), _lib.like_input(yvar, xtest))
+
+		xd = self._xd
+		xt = _lib.to_device(xtest, xd.dtype)
+		m, n = xt.shape[0], self.n
+		dt = _lib.dtype_code(xd.dtype)
+		st = _lib.stream_ptr
+		X = torch.empty((m, n), dtype=xd.dtype, device=xd.device)
+		ko._kernel_into(xd, xt, X)                                      # K* = k(x, xtest): (M, N)   :346
+		_lib.check(lib.stpy_trsm_right_lt(dt, m, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv),
+										  _lib.ptr(X), X.stride(0), self.nb, st()), "stpy_trsm_right_lt")   # X = K* L^-T
+		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
+		if not full:
+			kd = torch.empty((m,), dtype=xd.dtype, device=xd.device)
+			ko._diag_into(xt, kd)                                       # diag k(x*, x*)           :347
+			sigma = torch.empty((m,), dtype=xd.dtype, device=xd.device)
+			_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(self._z), _lib.ptr(kd), _lib.ptr(mu),
+										_lib.ptr(sigma), 1 if self.clamp_variance else 0, st()), "stpy_predict")
+			return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(sigma.reshape(-1, 1), xtest))
+		_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(self._z), None, _lib.ptr(mu),
+									None, 0, st()), "stpy_predict")
+		cov = torch.empty((m, m), dtype=xd.dtype, device=xd.device)
+		ko._kernel_into(xt, xt, cov)                                    # K**                      :343
+		_lib.check(lib.stpy_gemm_nt(dt, m, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(X), X.stride(0), _lib.ptr(cov),
+									cov.stride(0), 1, 0, st()), "stpy_gemm_nt")                    # K** - X X^T  :396-399
+		return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(cov, xtest))
+
+	def mean(self, xtest):
+		"""gauss_procc.py:403-418: K* alpha."""
+		lib = _lib.load()
+		xd = self._xd
+		xt = _lib.to_device(xtest, xd.dtype)
+		m, n = xt.shape[0], self.n
+		Ks = torch.empty((m, n), dtype=xd.dtype, device=xd.device)
+		self.kernel_object._kernel_into(xd, xt, Ks)
+		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
+		_lib.check(lib.stpy_predict(_lib.dtype_code(xd.dtype), m, n, _lib.ptr(Ks), Ks.stride(0), _lib.ptr(self._alpha), None,
+									_lib.ptr(mu), None, 0, _lib.stream_ptr()), "stpy_predict")
+		return _lib.like_input(mu.reshape(-1, 1), xtest)
+
+	# ------------------------------------------------------------------ evidence
+	def log_marginal(self, kernel, X, weight):
+		"""
+		gauss_procc.py:497-504 -> :631-638 (== estimator.py:32-40):
+		    1/2 y^T (K_theta + s^2 I)^-1 y + 1/2 * weight * log det(K_theta + s^2 I),   shape (1, 1).
+		Negative log evidence without the n/2 log(2 pi) constant.  ``X`` holds per-item parameter
+		overrides in the kwargs protocol of kernels.py:138-157.  With X empty and ``kernel`` the
+		fitted kernel object, the resident factor is reused.
+		"""
+		lib = _lib.load()
+		if self._xd is None:
+			if self.x is None:
+				raise AttributeError("log_marginal needs data: call fit_gp or load_data first")
+			self._xd = _lib.to_device(self.x)
+			self._yd = _lib.to_device(self.y, self._xd.dtype).reshape(-1, 1)
+			self.n = self._xd.shape[0]
+		reuse = self.fitted and (not X) and (kernel is self.kernel_object) and self._Sigma is None
+		if reuse:
+			L, z = self._L, self._z
+		else:
+			saved = self.kernel_object
+			self.kernel_object = kernel
+			try:
+				L, winv = self._factor(self._xd, X, None)
+			finally:
+				self.kernel_object = saved
+			z, _ = self._solve_y(L, winv, self._yd)
+		out2 = torch.empty((2,), dtype=L.dtype, device=L.device)
+		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(z), _lib.ptr(out2),
+										_lib.stream_ptr()), "stpy_logdet_quad")
+		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
+		val = 0.5 * out2[1] + 0.5 * w * 2.0 * out2[0]
+		return _lib.like_input(val.reshape(1, 1), self.x)
+
+	def load_data(self, d):
+		"""estimator.py:28-30."""
+		self.x = d[0]
+		self.y = d[1]
+		self._xd = self._yd = None
+		self.n = self.x.shape[0]

@@ -1,0 +1,153 @@
+// api.hip -- the extern "C" surface of libstpy_hip.so (see include/stpy_hip.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace stpy {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+int check_launch(const char* what)
+{
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+		return -1000 - (int)e;
+	}
+	return 0;
+}
+
+}  // namespace stpy
+
+using namespace stpy;
+
+#define DISPATCH(dtype, CALL64, CALL32)                                   \
+	do {                                                                  \
+		if ((dtype) == STPY_F64) return CALL64;                           \
+		if ((dtype) == STPY_F32) return CALL32;                           \
+		set_error("unknown dtype %d (0 = float64, 1 = float32)", dtype);  \
+		return -2;                                                        \
+	} while (0)
+
+extern "C" {
+
+const char* stpy_version(void) { return "stpy_hip 0.1 (gfx950)"; }
+const char* stpy_last_error_string(void) { return g_err; }
+
+int stpy_gram(int kind, int dtype, const void* a, int64_t n, int64_t lda, const void* b, int64_t q, int64_t ldb,
+              int d, const int32_t* cols, const void* inv_ls, double kappa, double offset, double diag_add,
+              int lower_only, int combine, void* out, int64_t ldo, void* stream)
+{
+	if (!a || !b || !out || !inv_ls) { set_error("stpy_gram: null pointer"); return -3; }
+	if (d <= 0 || lda < 1 || ldb < 1 || ldo < n) { set_error("stpy_gram: bad dimensions d=%d ldo=%lld n=%lld", d, (long long)ldo, (long long)n); return -9; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         gram<double>(kind, (const double*)a, n, lda, (const double*)b, q, ldb, d, cols, (const double*)inv_ls, kappa, offset, diag_add, lower_only, combine, (double*)out, ldo, st),
+	         gram<float>(kind, (const float*)a, n, lda, (const float*)b, q, ldb, d, cols, (const float*)inv_ls, kappa, offset, diag_add, lower_only, combine, (float*)out, ldo, st));
+}
+
+int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
+                   double kappa, double offset, int combine, void* out, void* stream)
+{
+	if (!x || !out || !inv_ls) { set_error("stpy_gram_diag: null pointer"); return -3; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         gram_diag<double>(kind, (const double*)x, m, ldx, d, cols, (const double*)inv_ls, kappa, offset, combine, (double*)out, st),
+	         gram_diag<float>(kind, (const float*)x, m, ldx, d, cols, (const float*)inv_ls, kappa, offset, combine, (float*)out, st));
+}
+
+int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
+{
+	if (nb <= 0) nb = 512;
+	return n * (int64_t)nb * (dtype == STPY_F64 ? 8 : 4);
+}
+
+int64_t stpy_potrf_winv_elems(int64_t n) { return ((n + IB - 1) / IB) * (int64_t)IB * IB; }
+
+int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int nb, int32_t* info_dev, void* stream)
+{
+	if (!A || !winv || !work || !info_dev) { set_error("stpy_potrf: null pointer"); return -3; }
+	if (n <= 0 || lda < n) { set_error("stpy_potrf: bad dimensions n=%lld lda=%lld", (long long)n, (long long)lda); return -2; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         potrf<double>(n, (double*)A, lda, (double*)winv, (double*)work, nb, info_dev, st),
+	         potrf<float>(n, (float*)A, lda, (float*)winv, (float*)work, nb, info_dev, st));
+}
+
+int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* stream)
+{
+	if (!L || !winv || !B) { set_error("stpy_trsm_right_lt: null pointer"); return -4; }
+	if (m < 0 || n <= 0 || ldl < n || ldb < n) { set_error("stpy_trsm_right_lt: bad dimensions"); return -2; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         trsm_right_lt<double>(m, n, (const double*)L, ldl, (const double*)winv, (double*)B, ldb, nb, st),
+	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st));
+}
+
+int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* y, void* out, int trans, void* stream)
+{
+	if (!L || !winv || !y || !out || y == out) { set_error("stpy_trsv: null or aliased pointer (y is scratch, out must differ)"); return -3; }
+	if (n <= 0 || ldl < n) { set_error("stpy_trsv: bad dimensions"); return -2; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         trsv<double>(n, (const double*)L, ldl, (const double*)winv, (double*)y, (double*)out, trans, st),
+	         trsv<float>(n, (const float*)L, ldl, (const float*)winv, (float*)y, (float*)out, trans, st));
+}
+
+int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, const void* z, const void* kdiag,
+                 void* mu, void* sigma, int clamp, void* stream)
+{
+	if (!X || !z || (sigma && !kdiag)) { set_error("stpy_predict: null pointer"); return -4; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         predict<double>(m, n, (const double*)X, ldx, (const double*)z, (const double*)kdiag, (double*)mu, (double*)sigma, clamp, st),
+	         predict<float>(m, n, (const float*)X, ldx, (const float*)z, (const float*)kdiag, (float*)mu, (float*)sigma, clamp, st));
+}
+
+int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const void* z, void* out2, void* stream)
+{
+	if (!L || !out2) { set_error("stpy_logdet_quad: null pointer"); return -3; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         logdet_quad<double>(n, (const double*)L, ldl, (const double*)z, (double*)out2, st),
+	         logdet_quad<float>(n, (const float*)L, ldl, (const float*)z, (float*)out2, st));
+}
+
+int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
+                 void* C, int64_t ldc, int mode, int lower_only, void* stream)
+{
+	if (!A || !B || !C) { set_error("stpy_gemm_nt: null pointer"); return -5; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         gemm_nt<double>(m, n, k, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, (double*)nullptr, 0, mode, lower_only, st),
+	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, lower_only, st));
+}
+
+int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stream)
+{
+	if (!A) { set_error("stpy_symmetrize_lower: null pointer"); return -3; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype, symmetrize_lower<double>(n, (double*)A, lda, st), symmetrize_lower<float>(n, (float*)A, lda, st));
+}
+
+int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, const void* W, int64_t ldw, int64_t m,
+                   const void* bias, double scale, void* out, int64_t ldo, void* stream)
+{
+	if (!x || !W || !out) { set_error("stpy_rff_embed: null pointer"); return -2; }
+	if (d <= 0 || ldx < d || ldw < d || ldo < m) { set_error("stpy_rff_embed: bad dimensions"); return -5; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, scale, (double*)out, ldo, st),
+	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, scale, (float*)out, ldo, st));
+}
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Shared declarations of libstpy_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/stpy_hip.h"
+
+namespace stpy {
+
+constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- MFMA 16x16x4 traits: the only thing that differs between f64 and f32 is the builtin and
+// ---- the C/D row map (cdna_hip_programming.md section 3: f64 row = (lane>>4) + 4*reg,
+// ---- f32 row = 4*(lane>>4) + reg); A/B: lane l holds A[l&15][k=l>>4], B[k=l>>4][l&15].
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+	typedef double v4 __attribute__((ext_vector_type(4)));
+	typedef double v2 __attribute__((ext_vector_type(2)));
+	static __device__ __forceinline__ v4 mma(double a, double b, v4 c) {
+		return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+	}
+	static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) + 4 * i; }
+};
+template <> struct Mfma<float> {
+	typedef float v4 __attribute__((ext_vector_type(4)));
+	typedef float v2 __attribute__((ext_vector_type(2)));
+	static __device__ __forceinline__ v4 mma(float a, float b, v4 c) {
+		return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+	}
+	static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) * 4 + i; }
+};
+
+// ---- internal launchers (all enqueue on `st`, return 0 or a negative error code) ----
+template <typename T>
+int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
+            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st);
+template <typename T>
+int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st);
+template <typename T>
+int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st);
+template <typename T>
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st);
+template <typename T>
+int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int trans, hipStream_t st);
+template <typename T>
+int predict(int64_t m, int64_t n, const T* X, int64_t ldx, const T* z, const T* kdiag, T* mu, T* sigma, int clamp, hipStream_t st);
+template <typename T>
+int logdet_quad(int64_t n, const T* L, int64_t ldl, const T* z, T* out2, hipStream_t st);
+template <typename T>
+int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st);
+template <typename T>
+int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, int64_t ldb, int d,
+         const int32_t* cols, const T* inv_ls, double kappa, double offset, double diag_add,
+         int lower_only, int combine, T* out, int64_t ldo, hipStream_t st);
+template <typename T>
+int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t* cols, const T* inv_ls,
+              double kappa, double offset, int combine, T* out, hipStream_t st);
+template <typename T>
+int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
+              const T* bias, double scale, T* out, int64_t ldo, hipStream_t st);
+
+}  // namespace stpy

@@ -1,0 +1,215 @@
+// gemm.hip -- C (op)= A * B^T on the 16x16x4 MFMA (fp64 / fp32), the dense contraction under the
+// blocked Cholesky (trailing SYRK/GEMM update, panel TRSM-as-GEMM) and the triangular solves.
+//
+// Shape of the problem on MI355X: v_mfma_f64_16x16x4_f64 retires 2048 flop per 64 SIMD-cycles,
+// so a wave that owns a 64x64 accumulator (16 MFMA tiles) needs only 8 operand fragments per
+// k-step: LDS traffic is ~1/16 of its bandwidth and the kernel is MFMA-issue bound.  What has to be
+// right is (a) operands staged through LDS in K-contiguous rows so both A and B (both stored
+// "row x K") use the same coalesced 16-byte loads, (b) two workgroups per CU (2 waves per SIMD) so
+// one workgroup's barrier / global-load latency hides under the other's MFMAs, (c) the block ->
+// tile map: 8x8 super-tiles, one super-tile per XCD at a time, so the 8+8 operand strips a
+// super-tile needs are served from that XCD's 4 MiB L2 instead of HBM.
+//
+// Lane/k mapping: MFMA lane l feeds A[row = l&15][k-slot = l>>4].  The sum over k is order
+// independent, so lane group g = l>>4 takes the four *consecutive* k values 4g..4g+3 of a 16-deep
+// K tile (two 16-byte LDS reads for f64) and MFMA number s of the tile uses element s of every
+// lane: k-slots {s, 4+s, 8+s, 12+s}.  A and B use the same map, which is all that is required.
+#include "common.h"
+
+namespace stpy {
+
+constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
+
+template <typename T>
+struct GemmArgs {
+	const T* A; const T* B; T* C; T* C2;
+	int64_t lda, ldb, ldc, ldc2;
+	int m, n, k;
+	int tiles_m, tiles_n;
+	int st_m, st_n;          // super-tile shape in tiles (st_m * st_n == 64)
+	int nst_m, nst_n;        // super-tile grid
+	int nsuper;              // number of super-tiles enumerated
+	int mode;                // 0: C = AB^T   1: C -= AB^T
+	int tri;                 // 1: lower-triangular tile set (square C), super-tiles enumerated over the lower triangle
+};
+
+template <typename T, bool GUARD>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_nt_kernel(GemmArgs<T> p)
+{
+	typedef Mfma<T> MM;
+	typedef typename MM::v4 v4;
+	typedef typename MM::v2 v2;
+	constexpr int CH = 16 / sizeof(T);        // elements per 16-byte chunk
+	constexpr int CPR = BK / CH;              // chunks per tile row
+	constexpr int RPP = NTHREADS / CPR;       // rows staged per pass
+	constexpr int NP = BM / RPP;              // passes per operand
+	constexpr int PAD = 16 / sizeof(T);       // one 16-byte chunk of padding per LDS row
+	constexpr int LLD = BK + PAD;
+	typedef T vch __attribute__((ext_vector_type(CH)));
+
+	__shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LLD];
+	T* As = smem;                         // [2][BM][LLD]
+	T* Bs = smem + 2 * BM * LLD;          // [2][BN][LLD]
+
+	// ---- block -> tile.  Blocks b, b+8, b+16.. share an XCD (round-robin dispatch; speed only):
+	// ---- super-tile S = (b % 8) + 8 * (b / 512), tile within it = (b / 8) % 64.
+	const int b = blockIdx.x;
+	const int S = (b & 7) + 8 * (b >> 9);
+	const int w = (b >> 3) & 63;
+	if (S >= p.nsuper) return;
+	int si, sj;
+	if (p.tri) {
+		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
+		while ((si + 1) * (si + 2) / 2 <= S) ++si;
+		while (si * (si + 1) / 2 > S) --si;
+		sj = S - si * (si + 1) / 2;
+	} else {
+		si = S / p.nst_n;
+		sj = S - si * p.nst_n;
+	}
+	const int ti = si * p.st_m + w / p.st_n;
+	const int tj = sj * p.st_n + w % p.st_n;
+	if (ti >= p.tiles_m || tj >= p.tiles_n) return;
+	if (p.tri && tj > ti) return;
+
+	const int row0 = ti * BM, col0 = tj * BN;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int wm = wave >> 1, wn = wave & 1;
+	const int r16 = lane & 15, g = lane >> 4;
+
+	// ---- global -> register staging map: thread owns chunk `lch` of rows lrow + pass*RPP
+	const int lrow = tid / CPR, lch = tid % CPR;
+	vch ra[NP], rb[NP];
+
+	auto gload = [&](int k0) {
+#pragma unroll
+		for (int q = 0; q < NP; ++q) {
+			const int r = lrow + q * RPP;
+			if (!GUARD) {
+				ra[q] = *(const vch*)(p.A + (int64_t)(row0 + r) * p.lda + k0 + lch * CH);
+				rb[q] = *(const vch*)(p.B + (int64_t)(col0 + r) * p.ldb + k0 + lch * CH);
+			} else {
+				const int ar = min(row0 + r, p.m - 1), br = min(col0 + r, p.n - 1);
+#pragma unroll
+				for (int e = 0; e < CH; ++e) {
+					const int kk = k0 + lch * CH + e;
+					const bool ok = kk < p.k;
+					const int kc = ok ? kk : 0;
+					T va = p.A[(int64_t)ar * p.lda + kc];
+					T vb = p.B[(int64_t)br * p.ldb + kc];
+					ra[q][e] = ok ? va : T(0);
+					rb[q][e] = ok ? vb : T(0);
+				}
+			}
+		}
+	};
+	auto lstore = [&](int buf) {
+#pragma unroll
+		for (int q = 0; q < NP; ++q) {
+			const int r = lrow + q * RPP;
+			*(vch*)(As + (buf * BM + r) * LLD + lch * CH) = ra[q];
+			*(vch*)(Bs + (buf * BN + r) * LLD + lch * CH) = rb[q];
+		}
+	};
+
+	v4 acc[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = v4{0, 0, 0, 0};
+
+	const int KT = (p.k + BK - 1) / BK;
+	gload(0);
+	lstore(0);
+	__syncthreads();
+	int buf = 0;
+	for (int kt = 0; kt < KT; ++kt) {
+		if (kt + 1 < KT) gload((kt + 1) * BK);
+		const T* as = As + (buf * BM + wm * 64 + r16) * LLD + g * 4;
+		const T* bs = Bs + (buf * BN + wn * 64 + r16) * LLD + g * 4;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			v2 fa[4], fb[4];
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				fa[t] = *(const v2*)(as + t * 16 * LLD + h * 2);
+				fb[t] = *(const v2*)(bs + t * 16 * LLD + h * 2);
+			}
+#pragma unroll
+			for (int s = 0; s < 2; ++s)
+#pragma unroll
+				for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn)
+						acc[tm][tn] = MM::mma(fa[tm][s], fb[tn][s], acc[tm][tn]);
+		}
+		if (kt + 1 < KT) lstore(buf ^ 1);
+		__syncthreads();
+		buf ^= 1;
+	}
+
+	// ---- epilogue: reg i of tile (tm,tn) is C[row0 + wm*64 + tm*16 + crow(lane,i)][col0 + wn*64 + tn*16 + r16]
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int row = row0 + wm * 64 + tm * 16 + MM::crow(lane, i);
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) {
+				const int col = col0 + wn * 64 + tn * 16 + r16;
+				if (GUARD && (row >= p.m || col >= p.n)) continue;
+				T v = acc[tm][tn][i];
+				T* cp = p.C + (int64_t)row * p.ldc + col;
+				if (p.mode == 1) v = *cp - v;
+				*cp = v;
+				if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v;
+			}
+		}
+}
+
+template <typename T>
+int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
+            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st)
+{
+	if (m <= 0 || n <= 0) return 0;
+	if (k <= 0) {
+		if (mode == 0) { set_error("gemm_nt: k == 0 with overwrite mode is not supported"); return -4; }
+		return 0;
+	}
+	if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) { set_error("gemm_nt: dimension exceeds int32"); return -2; }
+	GemmArgs<T> p;
+	p.A = A; p.B = B; p.C = C; p.C2 = C2;
+	p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2;
+	p.m = (int)m; p.n = (int)n; p.k = (int)k;
+	p.tiles_m = (int)((m + BM - 1) / BM);
+	p.tiles_n = (int)((n + BN - 1) / BN);
+	p.mode = mode;
+	p.tri = (lower_only && m == n) ? 1 : 0;
+	if (p.tri) {
+		p.st_m = ST; p.st_n = ST;
+	} else {
+		int sn = 1;
+		while (sn < ST && sn < p.tiles_n) sn *= 2;
+		p.st_n = sn; p.st_m = (ST * ST) / sn;
+	}
+	p.nst_m = (p.tiles_m + p.st_m - 1) / p.st_m;
+	p.nst_n = (p.tiles_n + p.st_n - 1) / p.st_n;
+	p.nsuper = p.tri ? p.nst_m * (p.nst_m + 1) / 2 : p.nst_m * p.nst_n;
+	const int64_t nblocks = (int64_t)((p.nsuper + 7) / 8) * 512;
+	if (nblocks > INT32_MAX) { set_error("gemm_nt: grid too large"); return -2; }
+	constexpr int CH = 16 / sizeof(T);
+	const bool aligned = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && (lda % CH == 0) && (ldb % CH == 0) &&
+	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
+	if (aligned)
+		hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3((unsigned)nblocks), dim3(NTHREADS), 0, st, p);
+	else
+		hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3((unsigned)nblocks), dim3(NTHREADS), 0, st, p);
+	return check_launch("gemm_nt");
+}
+
+template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t);
+template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t);
+
+}  // namespace stpy

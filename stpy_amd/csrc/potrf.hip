@@ -1,0 +1,174 @@
+// potrf.hip -- blocked right-looking Cholesky (lower), two levels:
+//   outer panels of nb columns (default 512): the trailing update A22 -= P P^T has K = nb, which
+//     puts the C read+write traffic at nb/8 flop per byte -- far on the MFMA side of the roofline;
+//   inner 128-column blocks, left-looking inside the panel: update block column from the panel
+//     so far (MFMA GEMM), factor + invert the 128x128 diagonal block in ONE workgroup (LDS
+//     resident, wave shuffles), then the sub-diagonal part by a GEMM with inverse(L_cc)^T.
+// Every O(n^3) and O(n^2 nb) term runs on the MFMA GEMM of gemm.hip; only the 128x128 diagonal
+// blocks (n/128 of them, ~0.7 Mflop each) run on the vector ALU.
+//
+// The factored panel is kept twice: in place in A (the result) and in a contiguous n x nb
+// workspace P (leading dimension nb) that the left-looking updates and the trailing update read:
+// rows of P are nb*8 bytes apart instead of lda*8, and the GEMM's two operands become the same
+// buffer.  inverse(L_cc) of every diagonal block is kept in `winv` for the triangular solves.
+#include "common.h"
+
+namespace stpy {
+
+constexpr int PT_THREADS = 512;
+constexpr int SLD = 132;     // LDS row stride in elements: 132 = 4 (mod 32) keeps the (row, k mod 4) lane map conflict-free
+
+// One workgroup: Cholesky of a (<=128)x(<=128) SPD block + inverse of its factor.
+//   A    : block in global memory (lower triangle read; L written back to the lower triangle)
+//   W    : 128x128 row-major, receives inverse(L) (zeros above the diagonal, identity padding)
+//   P2   : optional second copy of L (rows x 128 cols window of the panel workspace, zeros above the diagonal)
+// Thread map: 4 lanes per row (q = lane & 3 splits the k range), 128 rows -> 512 threads.
+template <typename T>
+__global__ __launch_bounds__(PT_THREADS)
+void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__ W,
+                        T* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	T* S = reinterpret_cast<T*>(smem_raw);          // [128][SLD]
+	T* dinv = S + IB * SLD;                         // [128]  1 / l_jj
+	T* ldiag = dinv + IB;                           // [128]  l_jj
+	const int tid = threadIdx.x;
+	const int row = tid >> 2, q = tid & 3;
+
+	// ---- load: lower triangle of the block, identity for the padding rows/cols
+	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
+		const int i = idx >> 7, j = idx & 127;
+		T v = T(0);
+		if (i < nbk && j <= i) v = A[(int64_t)i * lda + j];
+		else if (i >= nbk && i == j) v = T(1);
+		S[i * SLD + j] = v;
+	}
+	__syncthreads();
+
+	// ---- potf2, left-looking by column: t_i = a_ij - sum_{k<j} l_ik l_jk for all rows i >= j.
+	// ---- S[j][j] keeps the pivot d_j (never overwritten: everybody reads it between the two
+	// ---- barriers); l_jj and 1/l_jj live in ldiag / dinv.
+	for (int j = 0; j < IB; ++j) {
+		T part = T(0);
+		if (row >= j) {
+			const T* si = S + row * SLD;
+			const T* sj = S + j * SLD;
+			for (int k = q; k < j; k += 4) part += si[k] * sj[k];
+		}
+		part += __shfl_xor(part, 1);
+		part += __shfl_xor(part, 2);
+		if (row >= j && q == 0) S[row * SLD + j] -= part;
+		__syncthreads();
+		T d = S[j * SLD + j];
+		if (!(d > T(0)) || !(d < T(1e300))) {
+			if (tid == 0) atomicCAS(info, 0, block_row0 + j + 1);
+			d = T(1);
+		}
+		const T l = sqrt(d);
+		const T rl = T(1) / l;
+		if (q == 0) {
+			if (row > j) S[row * SLD + j] *= rl;
+			else if (row == j) { ldiag[j] = l; dinv[j] = rl; }
+		}
+		__syncthreads();
+	}
+
+	// ---- write L back (and the panel copy with explicit zeros above the diagonal)
+	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
+		const int i = idx >> 7, j = idx & 127;
+		if (i < nbk && j < nbk) {
+			const T v = (j < i) ? S[i * SLD + j] : (j == i ? ldiag[i] : T(0));
+			if (j <= i) A[(int64_t)i * lda + j] = v;
+			if (P2) P2[(int64_t)i * ldp2 + j] = v;
+		}
+	}
+	__syncthreads();
+
+	// ---- trtri: column c of W = inverse(L) by forward substitution, W[k][c] kept at S[c][k]
+	// ---- (k >= c: the strict upper triangle + diagonal of S, which L no longer needs).
+	{
+		const int c = row;
+		if (q == 0) S[c * SLD + c] = dinv[c];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// the four lanes of a column and all 16 columns of a wave run the i loop together; a
+		// column simply idles until i passes its own index
+		const int cmin = (tid >> 6) * 16;          // first column handled by this wave
+		for (int i = cmin + 1; i < IB; ++i) {
+			T part = T(0);
+			if (i > c) {
+				const T* li = S + i * SLD;
+				const T* wc = S + c * SLD;
+				for (int k = c + q; k < i; k += 4) part += li[k] * wc[k];
+			}
+			part += __shfl_xor(part, 1);
+			part += __shfl_xor(part, 2);
+			if (i > c && q == 0) S[c * SLD + i] = -part * dinv[i];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	__syncthreads();
+	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
+		const int i = idx >> 7, c = idx & 127;
+		W[idx] = (c <= i) ? S[c * SLD + i] : T(0);
+	}
+}
+
+template <typename T>
+int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st)
+{
+	const size_t lds = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
+	static bool attr_set[2] = {false, false};
+	const int which = sizeof(T) == 8 ? 0 : 1;
+	if (!attr_set[which]) {
+		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) { set_error("potf2: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e)); return -1000 - (int)e; }
+		attr_set[which] = true;
+	}
+	hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(PT_THREADS), lds, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	return check_launch("potf2_trtri");
+}
+
+template <typename T>
+int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st)
+{
+	if (nb <= 0) nb = 512;
+	if (nb % IB != 0) { set_error("potrf: nb must be a multiple of %d", IB); return -7; }
+	hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t), st);
+	if (e != hipSuccess) { set_error("potrf: memset(info) failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
+	T* P = work;                                   // n x nb, leading dimension nb, rows indexed globally
+	const int64_t ldp = nb;
+	int rc;
+	for (int64_t k = 0; k < n; k += nb) {
+		const int64_t kb = (n - k < nb) ? (n - k) : nb;
+		for (int64_t c = k; c < k + kb; c += IB) {
+			const int64_t cb = (n - c < IB) ? (n - c) : IB;
+			const int64_t jj = c - k;
+			if (jj > 0) {       // A[c:n, c:c+cb] -= P[c:n, 0:jj] P[c:c+cb, 0:jj]^T
+				rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st);
+				if (rc) return rc;
+			}
+			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st);
+			if (rc) return rc;
+			if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
+				rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
+				                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st);
+				if (rc) return rc;
+			}
+		}
+		if (k + kb < n) {       // trailing update, lower tiles only
+			const int64_t r = k + kb;
+			rc = gemm_nt<T>(n - r, n - r, kb, P + r * ldp, ldp, P + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 1, st);
+			if (rc) return rc;
+		}
+	}
+	return 0;
+}
+
+template int potf2_trtri<double>(double*, int64_t, int, double*, double*, int64_t, int32_t*, int, hipStream_t);
+template int potf2_trtri<float>(float*, int64_t, int, float*, float*, int64_t, int32_t*, int, hipStream_t);
+template int potrf<double>(int64_t, double*, int64_t, double*, double*, int, int32_t*, hipStream_t);
+template int potrf<float>(int64_t, float*, int64_t, float*, float*, int, int32_t*, hipStream_t);
+
+}  // namespace stpy

@@ -1,0 +1,262 @@
+// solve.hip -- everything downstream of the factor: B L^-T for blocks of right-hand sides (MFMA
+// GEMMs with the cached inverse diagonal blocks), L^-1 y / L^-T y for single vectors (HBM-bound
+// streaming of L), the fused prediction epilogue and the log-marginal reductions.
+#include "common.h"
+
+namespace stpy {
+
+// ------------------------------------------------------------------------------------------
+// B <- B L^-T,  B: m x n (rows = right-hand sides).  Same two-level blocking as potrf:
+// left-looking over 128-column blocks inside an nb-wide panel, right-looking between panels.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st)
+{
+	if (nb <= 0) nb = 512;
+	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
+	int rc;
+	for (int64_t k = 0; k < n; k += nb) {
+		const int64_t kb = (n - k < nb) ? (n - k) : nb;
+		for (int64_t c = k; c < k + kb; c += IB) {
+			const int64_t cb = (n - c < IB) ? (n - c) : IB;
+			const int64_t jj = c - k;
+			if (jj > 0) {   // B[:, c:c+cb] -= B[:, k:c] L[c:c+cb, k:c]^T
+				rc = gemm_nt<T>(m, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
+				if (rc) return rc;
+			}
+			// B[:, c:c+cb] <- B[:, c:c+cb] inverse(L_cc)^T   (one column tile => safe in place)
+			rc = gemm_nt<T>(m, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
+			if (rc) return rc;
+		}
+		if (k + kb < n) {   // B[:, k+kb:] -= B[:, k:k+kb] L[k+kb:, k:k+kb]^T
+			const int64_t r = k + kb;
+			rc = gemm_nt<T>(m, n - r, kb, B + k, ldb, L + r * ldl + k, ldl, B + r, ldb, (T*)nullptr, 0, 1, 0, st);
+			if (rc) return rc;
+		}
+	}
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Vector solves, blocked by 128 with the cached inverse(L_cc).  One launch per block step:
+// every workgroup recomputes the 128-vector  t = inverse(L_cc) y_c  (or its transpose form) in
+// LDS -- W is 128 KiB and L2-hot -- then streams its share of L once.  Workgroup 0 stores t into
+// `out`; updates go to the not-yet-solved part of y only, so there is no hazard on y_c.
+// ------------------------------------------------------------------------------------------
+constexpr int TV_THREADS = 256;
+constexpr int TV_ROWS = 256;     // rows of L per workgroup in the forward sweep
+constexpr int TV_COLS = 256;     // columns of L per workgroup in the backward sweep
+
+template <typename T>
+__global__ __launch_bounds__(TV_THREADS)
+void trsv_fwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W, T* __restrict__ y,
+                   T* __restrict__ out, int c, int cb, int n)
+{
+	__shared__ T yc[IB], tc[IB];
+	const int tid = threadIdx.x;
+	if (tid < IB) yc[tid] = tid < cb ? y[c + tid] : T(0);
+	__syncthreads();
+	// t = W y_c : two threads per row
+	{
+		const int r = tid >> 1, h = tid & 1;
+		T s = T(0);
+		const T* wr = W + r * IB + h * 64;
+		for (int k = 0; k < 64; ++k) s += wr[k] * yc[h * 64 + k];
+		s += __shfl_xor(s, 1);
+		if (h == 0) tc[r] = s;
+	}
+	__syncthreads();
+	if (blockIdx.x == 0) {
+		if (tid < cb) out[c + tid] = tc[tid];
+		return;
+	}
+	// y[r] -= L[r, c:c+cb] . t   for this workgroup's rows; 16 lanes per row, 8 elements per lane
+	const int row_base = c + cb + (blockIdx.x - 1) * TV_ROWS;
+	const int l16 = tid & 15, rsub = tid >> 4;            // 16 rows in flight per pass
+	T tv[8];
+#pragma unroll
+	for (int e = 0; e < 8; ++e) tv[e] = tc[l16 * 8 + e];
+	for (int r0 = 0; r0 < TV_ROWS; r0 += 16) {
+		const int r = row_base + r0 + rsub;
+		T s = T(0);
+		if (r < n) {
+			const T* lr = L + (int64_t)r * ldl + c + l16 * 8;
+#pragma unroll
+			for (int e = 0; e < 8; ++e) if (l16 * 8 + e < cb) s += lr[e] * tv[e];
+		}
+		s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+		if (r < n && l16 == 0) y[r] -= s;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(TV_THREADS)
+void trsv_bwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W, T* __restrict__ y,
+                   T* __restrict__ out, int c, int cb)
+{
+	__shared__ T yc[IB], tc[IB];
+	const int tid = threadIdx.x;
+	if (tid < IB) yc[tid] = tid < cb ? y[c + tid] : T(0);
+	__syncthreads();
+	// t = W^T y_c : t[k] = sum_i W[i][k] y_c[i]; lanes along k (coalesced), two halves of i
+	{
+		const int k = tid & 127, h = tid >> 7;
+		T s = T(0);
+		for (int i = h * 64; i < h * 64 + 64; ++i) s += W[i * IB + k] * yc[i];
+		if (h == 1) tc[k] = s;
+		__syncthreads();
+		if (h == 0) tc[k] += s;
+	}
+	__syncthreads();
+	if (blockIdx.x == 0) {
+		if (tid < cb) out[c + tid] = tc[tid];
+		return;
+	}
+	// y[j] -= sum_i L[c+i][j] t[i]  for this workgroup's columns j < c
+	const int j = (blockIdx.x - 1) * TV_COLS + tid;
+	if (j >= c) return;
+	T s = T(0);
+	const T* lp = L + (int64_t)c * ldl + j;
+	for (int i = 0; i < cb; ++i) s += lp[(int64_t)i * ldl] * tc[i];
+	y[j] -= s;
+}
+
+template <typename T>
+int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int trans, hipStream_t st)
+{
+	if (n > INT32_MAX) { set_error("trsv: n exceeds int32"); return -2; }
+	if (!trans) {
+		for (int64_t c = 0; c < n; c += IB) {
+			const int cb = (int)((n - c < IB) ? (n - c) : IB);
+			const int64_t rest = n - c - cb;
+			const unsigned grid = 1 + (unsigned)((rest + TV_ROWS - 1) / TV_ROWS);
+			hipLaunchKernelGGL((trsv_fwd_step<T>), dim3(grid), dim3(TV_THREADS), 0, st, L, ldl, winv + (c / IB) * IB * IB, y, out, (int)c, cb, (int)n);
+		}
+	} else {
+		const int64_t last = ((n - 1) / IB) * IB;
+		for (int64_t c = last; c >= 0; c -= IB) {
+			const int cb = (int)((n - c < IB) ? (n - c) : IB);
+			const unsigned grid = 1 + (unsigned)((c + TV_COLS - 1) / TV_COLS);
+			hipLaunchKernelGGL((trsv_bwd_step<T>), dim3(grid), dim3(TV_THREADS), 0, st, L, ldl, winv + (c / IB) * IB * IB, y, out, (int)c, cb);
+		}
+	}
+	return check_launch("trsv");
+}
+
+// ------------------------------------------------------------------------------------------
+// Prediction epilogue: one workgroup per test point streams its row of X = K* L^-T once.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void predict_kernel(const T* __restrict__ X, int64_t ldx, int n, const T* __restrict__ z,
+                    const T* __restrict__ kdiag, T* __restrict__ mu, T* __restrict__ sigma, int clamp)
+{
+	const int64_t i = blockIdx.x;
+	const T* xr = X + i * ldx;
+	T s1 = T(0), s2 = T(0);
+	for (int k = threadIdx.x; k < n; k += 256) {
+		const T v = xr[k];
+		s1 += v * z[k];
+		s2 += v * v;
+	}
+	__shared__ T r1[4], r2[4];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+	if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		s1 = r1[0] + r1[1] + r1[2] + r1[3];
+		s2 = r2[0] + r2[1] + r2[2] + r2[3];
+		if (mu) mu[i] = s1;
+		if (sigma) {
+			T var = kdiag[i] - s2;
+			if (clamp && var < T(0)) var = T(0);
+			sigma[i] = sqrt(var);
+		}
+	}
+}
+
+template <typename T>
+int predict(int64_t m, int64_t n, const T* X, int64_t ldx, const T* z, const T* kdiag, T* mu, T* sigma, int clamp, hipStream_t st)
+{
+	if (m <= 0) return 0;
+	if (n > INT32_MAX || m > INT32_MAX) { set_error("predict: dimension exceeds int32"); return -2; }
+	hipLaunchKernelGGL((predict_kernel<T>), dim3((unsigned)m), dim3(256), 0, st, X, ldx, (int)n, z, kdiag, mu, sigma, clamp);
+	return check_launch("predict");
+}
+
+// ------------------------------------------------------------------------------------------
+// out2[0] = sum log L_ii, out2[1] = z^T z.  Single workgroup, fixed summation order (bitwise
+// reproducible run to run).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024)
+void logdet_quad_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict__ z, int n, T* __restrict__ out2)
+{
+	T s1 = T(0), s2 = T(0);
+	for (int i = threadIdx.x; i < n; i += 1024) {
+		s1 += log(L[(int64_t)i * ldl + i]);
+		if (z) { const T v = z[i]; s2 += v * v; }
+	}
+	__shared__ T r1[16], r2[16];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+	if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		s1 = s2 = T(0);
+		for (int w = 0; w < 16; ++w) { s1 += r1[w]; s2 += r2[w]; }
+		out2[0] = s1; out2[1] = s2;
+	}
+}
+
+template <typename T>
+int logdet_quad(int64_t n, const T* L, int64_t ldl, const T* z, T* out2, hipStream_t st)
+{
+	if (n > INT32_MAX) { set_error("logdet_quad: n exceeds int32"); return -2; }
+	hipLaunchKernelGGL((logdet_quad_kernel<T>), dim3(1), dim3(1024), 0, st, L, ldl, z, (int)n, out2);
+	return check_launch("logdet_quad");
+}
+
+// ------------------------------------------------------------------------------------------
+// A[i][j] = A[j][i] for j > i, 64x64 tiles through LDS so both sides are coalesced.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void symmetrize_kernel(T* __restrict__ A, int64_t lda, int n)
+{
+	__shared__ T tile[64][65];
+	const int ti = blockIdx.y, tj = blockIdx.x;       // destination tile (row block ti, col block tj), tj >= ti
+	if (tj < ti) return;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	for (int r = ty; r < 64; r += 4) {                // source tile (tj, ti): rows tj*64.., cols ti*64..
+		const int gr = tj * 64 + r, gc = ti * 64 + tx;
+		tile[r][tx] = (gr < n && gc < n) ? A[(int64_t)gr * lda + gc] : T(0);
+	}
+	__syncthreads();
+	for (int r = ty; r < 64; r += 4) {
+		const int gr = ti * 64 + r, gc = tj * 64 + tx;
+		if (gr < n && gc < n && gc > gr) A[(int64_t)gr * lda + gc] = tile[tx][r];
+	}
+}
+
+template <typename T>
+int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	if (n > INT32_MAX) { set_error("symmetrize: n exceeds int32"); return -2; }
+	const unsigned t = (unsigned)((n + 63) / 64);
+	hipLaunchKernelGGL((symmetrize_kernel<T>), dim3(t, t), dim3(256), 0, st, A, lda, (int)n);
+	return check_launch("symmetrize_lower");
+}
+
+#define INST(T) \
+	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t); \
+	template int trsv<T>(int64_t, const T*, int64_t, const T*, T*, T*, int, hipStream_t); \
+	template int predict<T>(int64_t, int64_t, const T*, int64_t, const T*, const T*, T*, T*, int, hipStream_t); \
+	template int logdet_quad<T>(int64_t, const T*, int64_t, const T*, T*, hipStream_t); \
+	template int symmetrize_lower<T>(int64_t, T*, int64_t, hipStream_t);
+INST(double)
+INST(float)
+
+}  // namespace stpy

@@ -1,0 +1,355 @@
+"""
+End-to-end GPU parity of the drop-in classes (stpy_amd.KernelFunction / GaussianProcess /
+RFFEmbedding) against (a) the golden vectors produced by the real reference and (b) the CPU oracle,
+plus size-independent properties at BASELINE config sizes.  Tolerance: 1e-8 relative in fp64
+(BASELINE.json north_star), 1e-3 for the fp32 build-only modes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as O
+from tests.conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def S(gpu_device):
+	import stpy_amd
+	return stpy_amd
+
+
+def T(a, cuda=False):
+	t = torch.from_numpy(np.ascontiguousarray(a)).double()
+	return t.cuda() if cuda else t
+
+
+def N(t):
+	return t.detach().cpu().numpy()
+
+
+def check_gp(GP, g, prefix="", tol=TOL, cuda=False):
+	mu, std = GP.mean_std(T(g["xtest"], cuda))
+	assert mu.shape == g[prefix + "mu"].shape and std.shape == g[prefix + "std"].shape
+	assert mu.is_cuda == cuda
+	assert rel_err(N(mu), g[prefix + "mu"]) < tol
+	assert rel_err(N(std), g[prefix + "std"]) < tol
+	K = N(GP.get_kernel())
+	assert rel_err(K[:8, :8], g[prefix + "K_head"]) < 1e-12
+	assert abs(np.trace(K) - g[prefix + "K_trace"]) / g[prefix + "K_trace"] < 1e-12
+	assert abs(np.linalg.norm(K) - g[prefix + "K_fro"]) / g[prefix + "K_fro"] < 1e-12
+	assert np.abs(K - K.T).max() < 1e-13
+	assert rel_err(N(GP.A[:16]), g[prefix + "A_head"]) < tol * 100
+	assert abs(float(torch.norm(GP.A)) - g[prefix + "A_norm"]) / g[prefix + "A_norm"] < tol * 100
+
+
+def lml(GP, X=None, w=1.0):
+	v = GP.log_marginal(GP.kernel_object, {} if X is None else X, w)
+	assert tuple(v.shape) == (1, 1)
+	return float(v.item())
+
+
+def test_K1_kernels(S):
+	g = golden("K1_kernels")
+	a, b = T(g["a"]), T(g["b"])
+	KF = S.KernelFunction
+	ag = torch.tensor([0.5, 1.0, 2.0], dtype=torch.float64)
+	out = KF(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3).kernel(a, b)
+	assert tuple(out.shape) == (7, 5) and not out.is_cuda
+	assert rel_err(N(out), g["se"]) < 1e-13
+	assert rel_err(N(KF(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3, group=[0, 2]).kernel(a, b)), g["se_group"]) < 1e-13
+	assert rel_err(N(KF(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=3).kernel(a, b)), g["ard"]) < 1e-13
+	for nu in (0.5, 1.5, 2.5):
+		tag = str(nu).replace(".", "")
+		assert rel_err(N(KF(kernel_name="matern", gamma=1.7, nu=nu, kappa=1.1, d=3).kernel(a, b)), g["matern_" + tag]) < 1e-13
+		assert rel_err(N(KF(kernel_name="ard_matern", ard_gamma=ag, nu=nu, kappa=1.1, d=3).kernel(a, b)), g["ard_matern_" + tag]) < 1e-13
+	assert rel_err(N(KF(kernel_name="linear", kappa=2.0, d=3, offset=0.25).kernel(a, b)), g["linear"]) < 1e-14
+	k = KF(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3) + KF(kernel_name="matern", gamma=1.7, nu=2.5, kappa=0.5, d=3)
+	assert rel_err(N(k.kernel(a, b)), g["sum"]) < 1e-13
+	k = KF(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3) * KF(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=3)
+	assert rel_err(N(k.kernel(a, b)), g["prod"]) < 1e-13
+	kse = KF(kernel_name="squared_exponential", gamma=0.7, kappa=1.3, d=3)
+	for i, gam in enumerate(g["se_override_gammas"]):
+		out = kse.kernel(a, b, **{'0': {'gamma': torch.tensor(gam, dtype=torch.float64)}})
+		assert rel_err(N(out), g["se_override_%d" % i]) < 1e-13
+	assert rel_err(N(kse.kernel(a, b)), g["se"]) < 1e-13            # stored params untouched by overrides
+	ks = N(kse.kernel(T(g["x8"]), T(g["x8"])))
+	assert rel_err(ks, g["se_self"]) < 1e-13
+	assert np.abs(np.diag(ks) - 1.3).max() < 1e-14
+	# GPU-resident inputs give GPU-resident outputs
+	assert kse.kernel(a.cuda(), b.cuda()).is_cuda
+	with pytest.raises(NotImplementedError):
+		KF(kernel_name="laplace", d=3)
+	with pytest.raises(AssertionError):
+		KF(kernel_name="no_such_kernel", d=3)
+
+
+@pytest.mark.parametrize("name,tol", [("G1_c1_s001", 2e-6), ("G1_c1_s01", TOL)])
+@pytest.mark.parametrize("cuda", [False, True])
+def test_G1_config1(S, name, tol, cuda):
+	"""BASELINE config 1: 1-D SE GP, N=512 / M=256 (tutorial hyper-parameters)."""
+	g = golden(name)
+	GP = S.GaussianProcess(gamma=float(g["gamma"]), s=float(g["s"]), kappa=float(g["kappa"]), kernel_name="squared_exponential", d=1)
+	GP.fit_gp(T(g["x"], cuda), T(g["y"], cuda))
+	check_gp(GP, g, tol=tol, cuda=cuda)
+	assert abs(lml(GP) - g["lml"][0, 0]) / abs(g["lml"][0, 0]) < tol
+	assert abs(lml(GP, w=0.5) - g["lml_w05"][0, 0]) / abs(g["lml_w05"][0, 0]) < tol
+	# aliases named in BASELINE.json
+	mu2, std2 = GP.mean_var(T(g["xtest"], cuda))
+	assert rel_err(N(mu2), g["mu"]) < tol and rel_err(N(std2), g["std"]) < tol
+
+
+def test_G2_se_d8(S):
+	g = golden("G2_se_d8")
+	GP = S.GaussianProcess(gamma=1.0, s=0.1, kappa=1.7, kernel_name="squared_exponential", d=8)
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	check_gp(GP, g)
+	assert abs(lml(GP) - g["lml"][0, 0]) / abs(g["lml"][0, 0]) < TOL
+	kg = S.KernelFunction(kernel_name="squared_exponential", gamma=1.0, kappa=1.7, d=8, group=[0, 2, 5])
+	GPg = S.GaussianProcess(s=0.1, kernel=kg)
+	GPg.fit(T(g["x"]), T(g["y"]))
+	check_gp(GPg, g, prefix="group_")
+	assert abs(lml(GPg) - g["lml_group"][0, 0]) / abs(g["lml_group"][0, 0]) < TOL
+
+
+def test_G3_matern(S):
+	g = golden("G3_matern_d16")
+	for nu in (0.5, 1.5, 2.5):
+		tag = "nu%s_" % str(nu).replace(".", "")
+		GP = S.GaussianProcess(gamma=2.0, s=0.1, kappa=1.0, kernel_name="matern", nu=nu, d=16)
+		GP.fit_gp(T(g["x"]), T(g["y"]))
+		check_gp(GP, g, prefix=tag)
+		assert abs(lml(GP) - g[tag + "lml"][0, 0]) / abs(g[tag + "lml"][0, 0]) < TOL
+
+
+def test_G4_ard(S):
+	g = golden("G4_ard_d4")
+	ag = T(g["ard_gamma"])
+	GP = S.GaussianProcess(s=0.2, kernel=S.KernelFunction(kernel_name="ard", ard_gamma=ag, kappa=1.2, d=4))
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	check_gp(GP, g, prefix="ard_")
+	assert abs(lml(GP) - g["ard_lml"][0, 0]) / abs(g["ard_lml"][0, 0]) < TOL
+	v = lml(GP, {'0': {'ard_gamma': ag * 1.5}})
+	assert abs(v - g["ard_lml_override"][0, 0]) / abs(g["ard_lml_override"][0, 0]) < TOL
+	for nu in (1.5, 2.5):
+		tag = "ardm%s_" % str(nu).replace(".", "")
+		GP = S.GaussianProcess(s=0.2, kernel=S.KernelFunction(kernel_name="ard_matern", ard_gamma=ag, nu=nu, kappa=1.2, d=4))
+		GP.fit_gp(T(g["x"]), T(g["y"]))
+		check_gp(GP, g, prefix=tag)
+		assert abs(lml(GP) - g[tag + "lml"][0, 0]) / abs(g[tag + "lml"][0, 0]) < TOL
+
+
+def test_G5_composite(S):
+	g = golden("G5_composite")
+	KF = S.KernelFunction
+	GP = S.GaussianProcess(s=0.1, kernel=KF(kernel_name="squared_exponential", gamma=0.8, kappa=1.0, d=3) + KF(kernel_name="matern", gamma=1.5, nu=2.5, kappa=0.5, d=3))
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	check_gp(GP, g, prefix="sum_")
+	assert abs(lml(GP) - g["sum_lml"][0, 0]) / abs(g["sum_lml"][0, 0]) < TOL
+	GP = S.GaussianProcess(s=0.1, kernel=KF(kernel_name="squared_exponential", gamma=0.8, kappa=1.0, d=3) * KF(kernel_name="squared_exponential", gamma=2.0, kappa=0.7, d=3, group=[1, 2]))
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	check_gp(GP, g, prefix="prod_")
+	assert abs(lml(GP) - g["prod_lml"][0, 0]) / abs(g["prod_lml"][0, 0]) < TOL
+
+
+def test_G6_override_lml(S):
+	g = golden("G6_override_lml")
+	GP = S.GaussianProcess(gamma=0.5, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=2)
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	for i, gam in enumerate(g["gammas"]):
+		for j, w in enumerate(g["weights"]):
+			v = lml(GP, {'0': {'gamma': torch.tensor(gam, dtype=torch.float64)}}, float(w))
+			assert abs(v - g["lmls"][i, j]) / abs(g["lmls"][i, j]) < TOL
+	assert abs(lml(GP) - g["lml_default"][0, 0]) / abs(g["lml_default"][0, 0]) < TOL
+	# log_marginal without a prior fit (load_data path, estimator.py:28-30)
+	GP2 = S.GaussianProcess(gamma=0.5, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=2)
+	GP2.load_data((T(g["x"]), T(g["y"])))
+	assert abs(lml(GP2) - g["lml_default"][0, 0]) / abs(g["lml_default"][0, 0]) < TOL
+
+
+def test_G7_full_prior_execute(S):
+	g = golden("G7_full_prior")
+	xt = T(g["xtest"])
+	GP = S.GaussianProcess(gamma=0.6, s=0.1, kappa=1.4, kernel_name="squared_exponential", d=2)
+	mu0, cov0 = GP.mean_std(xt, full=True)
+	assert np.all(N(mu0) == 0) and rel_err(N(cov0), g["prior_full_cov"]) < 1e-13
+	mu0, std0 = GP.mean_std(xt)                      # reference raises here; the intended prior is returned
+	assert np.all(N(mu0) == 0) and np.allclose(N(std0), np.sqrt(1.4), rtol=0, atol=1e-15)
+	ks0, kss0 = GP.execute(xt)
+	assert ks0 is None and rel_err(N(kss0), g["prior_kss"]) < 1e-13
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	mu, cov = GP.mean_std(xt, full=True)
+	assert rel_err(N(mu), g["full_mu"]) < TOL
+	assert rel_err(N(cov), g["full_cov"]) < TOL
+	ks, kss = GP.execute(xt)
+	assert tuple(ks.shape) == g["exec_ks"].shape
+	assert rel_err(N(ks), g["exec_ks"]) < 1e-13 and rel_err(N(kss), g["exec_kss"]) < 1e-13
+	assert rel_err(N(GP.mean(xt)), g["mean"]) < TOL
+	assert rel_err(N(GP.ucb(xt)), g["ucb"]) < TOL and rel_err(N(GP.lcb(xt)), g["lcb"]) < TOL
+
+
+def test_G8_chunked(S):
+	g = golden("G8_chunked")
+	GP = S.GaussianProcess(gamma=0.6, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=2)
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	GP.max_size = int(g["max_size"])
+	mu, std = GP.mean_std(T(g["xtest"]))
+	assert tuple(mu.shape) == g["mu"].shape
+	assert rel_err(N(mu), g["mu"]) < TOL and rel_err(N(std), g["std"]) < TOL
+
+
+def test_G9_add_data_point(S):
+	g = golden("G9_add_data_point")
+	GP = S.GaussianProcess(gamma=0.6, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=2)
+	for i in range(3):
+		GP.add_data_point(T(g["x%d" % i]), T(g["y%d" % i]))
+	assert GP.n == int(g["n"])
+	check_gp(GP, g)
+	GP2 = S.GaussianProcess(gamma=0.6, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=2)
+	for i in range(3):
+		GP2.add_data(T(g["x%d" % i]), T(g["y%d" % i]))
+	check_gp(GP2, g)
+
+
+def test_G10_rff(S):
+	g = golden("G10_rff")
+	m, d = int(g["m"]), g["W"].shape[1]
+	x = T(g["x"])
+	emb = S.RFFEmbedding(gamma=0.7, m=m, d=d, kappa=1.0)
+	assert tuple(emb.W.shape) == (m, d) and emb.get_m() == m
+	emb.W = T(g["W"])
+	z = emb.embed(x)
+	assert tuple(z.shape) == g["z"].shape and rel_err(N(z), g["z"]) < 1e-14
+	emb2 = S.RFFEmbedding(gamma=0.7, m=m, d=d, kappa=2.5)
+	emb2.W = T(g["W"])
+	assert rel_err(N(emb2.embed(x)), g["z_kappa25"]) < 1e-14
+	embb = S.RFFEmbedding(gamma=0.7, m=m, d=d, kappa=2.5, biased=True)
+	embb.W, embb.b = T(g["W"]), T(g["b"])
+	zb = embb.embed(x)
+	assert tuple(zb.shape) == g["z_biased_kappa25"].shape          # (m, n): the reference's double transpose
+	assert rel_err(N(zb), g["z_biased_kappa25"]) < 1e-14
+	assert rel_err(N(emb.embed(x[:, :3])), g["z_sub3"]) < 1e-14
+	np.random.seed(0)
+	assert rel_err(N(S.RFFEmbedding(gamma=0.7, m=8, d=3).W), g["W_seed0"]) < 1e-15
+	np.random.seed(0)
+	eb = S.RFFEmbedding(gamma=0.7, m=8, d=3, biased=True)
+	assert rel_err(N(eb.W), g["W_seed0_biased"]) < 1e-15 and rel_err(N(eb.b), g["b_seed0_biased"]) < 1e-15
+	with pytest.raises(AssertionError):
+		S.RFFEmbedding(gamma=0.7, m=7, d=3)
+	# RFF features approximate the SE kernel: Phi Phi^T -> k(x, x) as m grows (sanity of the layout)
+	np.random.seed(1)
+	big = S.RFFEmbedding(gamma=0.7, m=8192, d=d)
+	Phi = N(big.embed(x))
+	Kse = O.squared_exponential(g["x"], g["x"], 0.7)
+	assert np.abs(Phi @ Phi.T - Kse).max() < 0.06
+
+
+def test_G11_lu_branch_and_helpers(S):
+	g = golden("G11_lu_branch")
+	GP = S.GaussianProcess(gamma=1.0, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=3)
+	GP.back_prop = False
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	mu, std = GP.mean_std(T(g["xtest"]))
+	assert rel_err(N(mu), g["mu_lu"]) < TOL and rel_err(N(std), g["std_lu"]) < TOL
+	from stpy_amd.helpers import helper
+	h = golden("H1_helpers")
+	assert np.array_equal(helper.interval(5, 2), h["interval_5_2"])
+	assert np.array_equal(helper.interval(4, 1, L_infinity_ball=0.5), h["interval_4_1_half"])
+	assert np.array_equal(helper.cartesian([np.array([1., 2.]), np.array([3., 4., 5.])]), h["cartesian_2x3"])
+
+
+def test_not_positive_definite_raises(S):
+	x = torch.zeros((300, 2), dtype=torch.float64)        # 300 identical points, no noise -> singular
+	GP = S.GaussianProcess(gamma=1.0, s=0.0, kappa=1.0, kernel_name="squared_exponential", d=2)
+	with pytest.raises(torch.linalg.LinAlgError):
+		GP.fit_gp(x, torch.zeros((300, 1), dtype=torch.float64))
+	with pytest.raises(NotImplementedError):
+		S.GaussianProcess(loss="huber")
+
+
+# --------------------------------------------------------------------------------------------
+# larger sizes: oracle where it finishes in seconds, properties beyond
+# --------------------------------------------------------------------------------------------
+
+def synth(n, d, m, seed=1234):
+	"""SURVEY.md section 8d generator: x ~ U(-1,1)^{n x d}, y = sin(sum x) + 0.1 N(0,1), xtest ~ U(-1,1)."""
+	gx = torch.Generator().manual_seed(seed)
+	x = torch.rand(n, d, generator=gx, dtype=torch.float64) * 2 - 1
+	gy = torch.Generator().manual_seed(seed + 1)
+	y = torch.sin(x.sum(dim=1, keepdim=True)) + 0.1 * torch.randn(n, 1, generator=gy, dtype=torch.float64)
+	gt = torch.Generator().manual_seed(seed + 2)
+	xt = torch.rand(m, d, generator=gt, dtype=torch.float64) * 2 - 1
+	return x, y, xt
+
+
+@pytest.mark.parametrize("kernel_name,nu", [("squared_exponential", None), ("matern", 2.5)])
+def test_mid_size_vs_oracle(S, kernel_name, nu):
+	n, d, m = 4096, 8, 512
+	x, y, xt = synth(n, d, m)
+	gamma, s = float(np.sqrt(d)), 0.1
+	kw = dict(nu=nu) if nu else {}
+	GP = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name=kernel_name, d=d, **kw)
+	GP.fit_gp(x.cuda(), y.cuda())
+	mu, std = GP.mean_std(xt.cuda())
+	spec = [(kernel_name, dict(gamma=gamma, kappa=1.0, **kw), "-")]
+	L, alpha = O.fit(x.numpy(), y.numpy(), spec, s)
+	mu_o, std_o = O.mean_std(x.numpy(), L, alpha, xt.numpy(), spec)
+	assert rel_err(N(mu), mu_o) < TOL and rel_err(N(std), std_o) < TOL
+	assert rel_err(N(GP.A), alpha) < 1e-6
+	lm_o = O.log_marginal(x.numpy(), y.numpy(), spec, s)[0, 0]
+	assert abs(lml(GP) - lm_o) / abs(lm_o) < TOL
+
+
+def test_config2_properties(S):
+	"""BASELINE config 2: N=16 384, d=8 SE, fp64.  Size-independent checks: (K+s^2 I) alpha = y,
+	interpolation-consistency of mean(x) = K alpha, 0 <= sigma <= sqrt(kappa), a 2 048-point oracle
+	sub-problem, and linearity of the posterior mean in y."""
+	n, d, m = 16384, 8, 4096
+	x, y, xt = synth(n, d, m)
+	gamma, s = float(np.sqrt(d)), 0.1
+	xd, yd, xtd = x.cuda(), y.cuda(), xt.cuda()
+	GP = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(xd, yd)
+	mu, std = GP.mean_std(xtd)
+	K = GP.K
+	r = K @ GP.A - yd
+	assert float(torch.norm(r) / torch.norm(yd)) < 1e-10
+	del K
+	assert bool(torch.all(std >= 0)) and bool(torch.all(std <= 1.0 + 1e-12)) and not bool(torch.isnan(std).any())
+	assert rel_err(N(GP.mean(xtd)), N(mu)) < 1e-9
+	# linearity: fit on 2y - 3 -> mean = 2 mu - 3 * K* K^-1 1; check through a second right-hand side
+	GP2 = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP2.fit_gp(xd, 2.0 * yd)
+	mu2, std2 = GP2.mean_std(xtd)
+	assert rel_err(N(mu2), 2 * N(mu)) < 1e-10 and rel_err(N(std2), N(std)) < 1e-12
+	# oracle on a sub-problem of the same data
+	ns = 2048
+	GPs = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GPs.fit_gp(xd[:ns], yd[:ns])
+	mus, stds = GPs.mean_std(xtd[:256])
+	spec = [("squared_exponential", {"gamma": gamma, "kappa": 1.0}, "-")]
+	Lo, ao = O.fit(x[:ns].numpy(), y[:ns].numpy(), spec, s)
+	mo, so = O.mean_std(x[:ns].numpy(), Lo, ao, xt[:256].numpy(), spec)
+	assert rel_err(N(mus), mo) < TOL and rel_err(N(stds), so) < TOL
+
+
+def test_fp32_mode(S):
+	"""fp32 is a build-only precision mode (the reference is fp64-only); oracle = fp64 on the same
+	(up-cast) inputs, tolerance 1e-3 with s >= 0.3 (hard parts)."""
+	n, d, m = 2048, 16, 256
+	x, y, xt = synth(n, d, m)
+	x32, y32, xt32 = x.float(), y.float(), xt.float()
+	gamma, s = float(np.sqrt(d)), 0.3
+	GP = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="matern", nu=2.5, d=d)
+	GP.fit_gp(x32.cuda(), y32.cuda())
+	mu, std = GP.mean_std(xt32.cuda())
+	assert mu.dtype == torch.float32
+	spec = [("matern", {"gamma": gamma, "nu": 2.5, "kappa": 1.0}, "-")]
+	L, alpha = O.fit(x32.double().numpy(), y32.double().numpy(), spec, s)
+	mu_o, std_o = O.mean_std(x32.double().numpy(), L, alpha, xt32.double().numpy(), spec)
+	assert rel_err(N(mu).astype(np.float64), mu_o) < 1e-3 and rel_err(N(std).astype(np.float64), std_o) < 1e-3
+	lm_o = O.log_marginal(x32.double().numpy(), y32.double().numpy(), spec, s)[0, 0]
+	assert abs(lml(GP) - lm_o) / abs(lm_o) < 1e-3

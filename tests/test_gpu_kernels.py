@@ -1,0 +1,323 @@
+"""
+GPU parity tests of the individual C-ABI entry points (include/stpy_hip.h) against the CPU oracle /
+numpy on the same seeded inputs.  Run with `-m gpu` on an MI355X.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+from oracle import gp_oracle as O
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-11
+
+
+@pytest.fixture(scope="module")
+def L(gpu_device):
+	from stpy_amd import _lib
+	return _lib
+
+
+def dev(a, dtype=torch.float64):
+	return torch.from_numpy(np.ascontiguousarray(a)).to(device="cuda:0", dtype=dtype)
+
+
+def spd(rng, n, d=4, s=0.3):
+	x = rng.uniform(-1, 1, size=(n, d))
+	return O.gram_train(x, [("squared_exponential", {"gamma": 1.0, "kappa": 1.0}, "-")], s)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 384, 128), (300, 200, 70), (1, 130, 5), (513, 129, 257), (1024, 1024, 512)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gemm_nt(L, m, n, k, mode):
+	rng = np.random.RandomState(m * 7 + n * 3 + k + mode)
+	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+	Ad, Bd, Cd = dev(A), dev(B), dev(C)
+	lib = L.load()
+	rc = lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr())
+	L.check(rc, "gemm")
+	ref = A @ B.T if mode == 0 else C - A @ B.T
+	assert rel_err(Cd.cpu().numpy(), ref) < 1e-14 * max(1, k) ** 0.5 * 10
+
+
+def test_gemm_nt_asymmetric_layout(L):
+	"""A = I with an asymmetric B: catches a transposed C/D fragment map (cdna guide section 3)."""
+	n = 128
+	A = np.eye(n)
+	B = np.arange(n * n, dtype=np.float64).reshape(n, n) / 7.0
+	Ad, Bd, Cd = dev(A), dev(B), dev(np.zeros((n, n)))
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt(L.F64, n, n, n, L.ptr(Ad), n, L.ptr(Bd), n, L.ptr(Cd), n, 0, 0, L.stream_ptr()), "gemm")
+	assert np.array_equal(Cd.cpu().numpy(), B.T)
+
+
+@pytest.mark.parametrize("n,k", [(512, 128), (1280, 512), (1000, 96)])
+def test_gemm_nt_lower_only(L, n, k):
+	rng = np.random.RandomState(n + k)
+	P, C = rng.normal(size=(n, k)), rng.normal(size=(n, n))
+	Pd, Cd = dev(P), dev(C)
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(Pd), k, L.ptr(Pd), k, L.ptr(Cd), n, 1, 1, L.stream_ptr()), "gemm")
+	out = Cd.cpu().numpy()
+	ref = C - P @ P.T
+	il = np.tril_indices(n)
+	assert rel_err(out[il], ref[il]) < 1e-13
+	# tiles strictly above the diagonal are untouched
+	tiles = (n + 127) // 128
+	for ti in range(tiles):
+		for tj in range(ti + 1, tiles):
+			blk = (slice(ti * 128, min(n, ti * 128 + 128)), slice(tj * 128, min(n, tj * 128 + 128)))
+			assert np.array_equal(out[blk], C[blk])
+
+
+def test_gemm_nt_strided_submatrix(L):
+	"""Leading dimensions larger than the logical width, operands inside bigger buffers."""
+	rng = np.random.RandomState(5)
+	big = rng.normal(size=(700, 900))
+	bd = dev(big)
+	m, n, k = 256, 128, 384
+	A = big[128:128 + m, 256:256 + k]
+	B = big[400:400 + n, 256:256 + k]
+	C = rng.normal(size=(m, n))
+	Cd = dev(C)
+	lib = L.load()
+	es = 8
+	pa = ctypes.c_void_p(bd.data_ptr() + (128 * 900 + 256) * es)
+	pb = ctypes.c_void_p(bd.data_ptr() + (400 * 900 + 256) * es)
+	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, pa, 900, pb, 900, L.ptr(Cd), n, 1, 0, L.stream_ptr()), "gemm")
+	assert rel_err(Cd.cpu().numpy(), C - A @ B.T) < 1e-13
+
+
+def test_gemm_nt_f32(L):
+	rng = np.random.RandomState(9)
+	m, n, k = 384, 256, 200
+	A, B = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(n, k)).astype(np.float32)
+	Ad, Bd = dev(A, torch.float32), dev(B, torch.float32)
+	Cd = torch.zeros((m, n), dtype=torch.float32, device="cuda:0")
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt(L.F32, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, 0, 0, L.stream_ptr()), "gemm")
+	assert rel_err(Cd.cpu().numpy(), A.astype(np.float64) @ B.astype(np.float64).T) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------ Gram
+KINDS = [("se", 0), ("m12", 1), ("m32", 2), ("m52", 3), ("lin", 4)]
+
+
+def oracle_gram(kind, a, b, inv_ls, kappa, offset, cols):
+	ls = 1.0 / np.asarray(inv_ls)
+	group = list(cols) if cols is not None else None
+	if kind == 0:
+		g = np.ones(a.shape[1]); g[group if group else slice(None)] = ls
+		return O.ard(a, b, g, kappa, group)
+	if kind in (1, 2, 3):
+		g = np.ones(a.shape[1]); g[group if group else slice(None)] = ls
+		aa, bb = a / g, b / g
+		return O.matern(aa, bb, 1.0, {1: 0.5, 2: 1.5, 3: 2.5}[kind], kappa, group)
+	return O.linear(a, b, kappa, offset, group)
+
+
+@pytest.mark.parametrize("name,kind", KINDS)
+@pytest.mark.parametrize("n,q,d", [(5, 7, 3), (128, 64, 16), (300, 131, 1), (257, 513, 33)])
+def test_gram_kinds(L, name, kind, n, q, d):
+	rng = np.random.RandomState(n + q + d + kind)
+	a, b = rng.uniform(-1, 1, size=(n, d)), rng.uniform(-1, 1, size=(q, d))
+	inv_ls = rng.uniform(0.3, 1.5, size=d) if kind != 4 else np.ones(d)
+	ad, bd, ild = dev(a), dev(b), dev(inv_ls)
+	out = torch.empty((q, n), dtype=torch.float64, device="cuda:0")
+	lib = L.load()
+	L.check(lib.stpy_gram(kind, L.F64, L.ptr(ad), n, d, L.ptr(bd), q, d, d, None, L.ptr(ild), 1.3, 0.25, 0.0, 0, 0,
+						  L.ptr(out), n, L.stream_ptr()), "gram")
+	ref = oracle_gram(kind, a, b, inv_ls, 1.3, 0.25, None)
+	assert out.shape == (q, n)
+	assert rel_err(out.cpu().numpy(), ref) < 1e-13
+
+
+def test_gram_cols_combine_diag_lower(L):
+	rng = np.random.RandomState(3)
+	n, d = 333, 6
+	x = rng.uniform(-1, 1, size=(n, d))
+	xd = dev(x)
+	cols = [0, 2, 5]
+	inv_ls = np.array([1.0, 0.5, 2.0])
+	colsd = torch.tensor(cols, dtype=torch.int32, device="cuda:0")
+	lib = L.load()
+	out = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(dev(inv_ls)), 1.1, 0.0, 0.0, 0, L.OUT_SET,
+						  L.ptr(out), n, L.stream_ptr()), "gram")
+	k1 = oracle_gram(0, x, x, inv_ls, 1.1, 0.0, cols)
+	assert rel_err(out.cpu().numpy(), k1) < 1e-13
+	# product with a Matern 5/2 on all columns, then diag_add on the last item
+	il2 = np.full(d, 0.7)
+	L.check(lib.stpy_gram(3, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, d, None, L.ptr(dev(il2)), 0.9, 0.0, 0.04, 0, L.OUT_MUL,
+						  L.ptr(out), n, L.stream_ptr()), "gram")
+	k2 = k1 * oracle_gram(3, x, x, il2, 0.9, 0.0, None) + 0.04 * np.eye(n)
+	assert rel_err(out.cpu().numpy(), k2) < 1e-13
+	# lower_only: lower triangle identical, sum with ADD
+	out2 = torch.full((n, n), 7.0, dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(dev(inv_ls)), 1.1, 0.0, 0.5, 1, L.OUT_SET,
+						  L.ptr(out2), n, L.stream_ptr()), "gram")
+	o2 = out2.cpu().numpy()
+	il = np.tril_indices(n)
+	assert rel_err(o2[il], (k1 + 0.5 * np.eye(n))[il]) < 1e-13
+	assert o2[0, n - 1] == 7.0          # far upper-right tile untouched
+
+
+def test_gram_diag_and_symmetrize(L):
+	rng = np.random.RandomState(4)
+	m, d = 77, 5
+	x = rng.uniform(-1, 1, size=(m, d))
+	xd = dev(x)
+	lib = L.load()
+	out = torch.empty((m,), dtype=torch.float64, device="cuda:0")
+	il = dev(np.full(d, 0.5))
+	L.check(lib.stpy_gram_diag(0, L.F64, L.ptr(xd), m, d, d, None, L.ptr(il), 1.7, 0.0, L.OUT_SET, L.ptr(out), L.stream_ptr()), "diag")
+	assert np.allclose(out.cpu().numpy(), 1.7, rtol=0, atol=0)
+	L.check(lib.stpy_gram_diag(4, L.F64, L.ptr(xd), m, d, d, None, L.ptr(dev(np.ones(d))), 2.0, 0.5, L.OUT_ADD, L.ptr(out), L.stream_ptr()), "diag")
+	assert rel_err(out.cpu().numpy(), 1.7 + 2.0 * np.sum(x * x, axis=1) + 0.5) < 1e-14
+	n = 200
+	A = rng.normal(size=(n, n))
+	Ad = dev(A)
+	L.check(lib.stpy_symmetrize_lower(L.F64, n, L.ptr(Ad), n, L.stream_ptr()), "sym")
+	ref = np.tril(A) + np.tril(A, -1).T
+	assert np.array_equal(Ad.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------------------ factorisation + solves
+def run_potrf(L, K, nb=0, dtype=torch.float64):
+	lib = L.load()
+	n = K.shape[0]
+	Kd = dev(K, dtype)
+	code = L.dtype_code(dtype)
+	winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=dtype, device="cuda:0")
+	work = torch.empty((int(lib.stpy_potrf_workspace_bytes(code, n, nb)),), dtype=torch.uint8, device="cuda:0")
+	info = torch.full((1,), -5, dtype=torch.int32, device="cuda:0")
+	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(work), nb, L.ptr(info), L.stream_ptr()), "potrf")
+	return Kd, winv, int(info.item())
+
+
+@pytest.mark.parametrize("n,nb", [(1, 0), (64, 0), (128, 0), (129, 0), (200, 128), (512, 256), (1000, 256), (1536, 512), (2049, 512), (3000, 0)])
+def test_potrf(L, n, nb):
+	rng = np.random.RandomState(n)
+	K = spd(rng, n)
+	Ld, winv, info = run_potrf(L, K, nb)
+	assert info == 0
+	Lg = np.tril(Ld.cpu().numpy())
+	Lref = np.linalg.cholesky(K)
+	assert rel_err(Lg, Lref) < 1e-12
+	assert rel_err(Lg @ Lg.T, K) < 1e-14
+	# cached inverse diagonal blocks
+	W = winv.cpu().numpy().reshape(-1, 128, 128)
+	for bi in range(W.shape[0]):
+		c = bi * 128
+		cb = min(128, n - c)
+		Wref = np.linalg.inv(Lref[c:c + cb, c:c + cb])
+		assert rel_err(W[bi][:cb, :cb], Wref) < 1e-11
+		assert np.all(np.triu(W[bi], 1) == 0)
+
+
+def test_potrf_not_positive_definite(L):
+	rng = np.random.RandomState(0)
+	n = 300
+	K = spd(rng, n)
+	K[170, 170] = -1.0
+	_, _, info = run_potrf(L, K, 128)
+	assert info == 171          # LAPACK convention: order of the failing leading minor
+
+
+@pytest.mark.parametrize("n,m,nb", [(128, 5, 0), (200, 130, 128), (1000, 77, 256), (1536, 256, 512), (2049, 300, 512)])
+def test_trsm_trsv_predict_logdet(L, n, m, nb):
+	rng = np.random.RandomState(n + m)
+	K = spd(rng, n)
+	Ld, winv, info = run_potrf(L, K, nb)
+	assert info == 0
+	Lref = np.linalg.cholesky(K)
+	lib = L.load()
+	B = rng.normal(size=(m, n))
+	Bd = dev(B)
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, nb, L.stream_ptr()), "trsm")
+	Xref = sla.solve_triangular(Lref, B.T, lower=True).T
+	assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
+	y = rng.normal(size=n)
+	yd, zd, ad = dev(y), torch.empty(n, dtype=torch.float64, device="cuda:0"), torch.empty(n, dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
+	zref = sla.solve_triangular(Lref, y, lower=True)
+	assert rel_err(zd.cpu().numpy(), zref) < 1e-11
+	zs = zd.clone()
+	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(zs), L.ptr(ad), 1, L.stream_ptr()), "trsv")
+	aref = sla.solve_triangular(Lref.T, zref, lower=False)
+	assert rel_err(ad.cpu().numpy(), aref) < 1e-10
+	kdiag = np.full(m, 5.0 + np.max(np.sum(Xref * Xref, axis=1)))
+	mu, sg = torch.empty(m, dtype=torch.float64, device="cuda:0"), torch.empty(m, dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_predict(L.F64, m, n, L.ptr(Bd), n, L.ptr(zd), L.ptr(dev(kdiag)), L.ptr(mu), L.ptr(sg), 0, L.stream_ptr()), "predict")
+	assert rel_err(mu.cpu().numpy(), Xref @ zref) < 1e-11
+	assert rel_err(sg.cpu().numpy(), np.sqrt(kdiag - np.sum(Xref * Xref, axis=1))) < 1e-12
+	out2 = torch.empty(2, dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_logdet_quad(L.F64, n, L.ptr(Ld), n, L.ptr(zd), L.ptr(out2), L.stream_ptr()), "logdet")
+	o = out2.cpu().numpy()
+	assert abs(o[0] - np.sum(np.log(np.diag(Lref)))) < 1e-10 * max(1.0, abs(o[0]))
+	assert abs(o[1] - zref @ zref) < 1e-10 * abs(zref @ zref)
+
+
+def test_predict_negative_variance_is_nan_unless_clamped(L):
+	"""gauss_procc.py:394-395: sqrt of an unclamped difference."""
+	lib = L.load()
+	X = dev(np.array([[2.0, 0.0], [0.5, 0.5]]))
+	z = dev(np.array([1.0, 1.0]))
+	kd = dev(np.array([1.0, 1.0]))
+	mu, sg = torch.empty(2, dtype=torch.float64, device="cuda:0"), torch.empty(2, dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_predict(L.F64, 2, 2, L.ptr(X), 2, L.ptr(z), L.ptr(kd), L.ptr(mu), L.ptr(sg), 0, L.stream_ptr()), "predict")
+	s = sg.cpu().numpy()
+	assert np.isnan(s[0]) and abs(s[1] - np.sqrt(0.5)) < 1e-15
+	L.check(lib.stpy_predict(L.F64, 2, 2, L.ptr(X), 2, L.ptr(z), L.ptr(kd), L.ptr(mu), L.ptr(sg), 1, L.stream_ptr()), "predict")
+	assert sg.cpu().numpy()[0] == 0.0
+
+
+def test_potrf_f32(L):
+	rng = np.random.RandomState(11)
+	n = 1000
+	K = spd(rng, n, s=0.5)
+	Ld, winv, info = run_potrf(L, K.astype(np.float32), 256, torch.float32)
+	assert info == 0
+	Lg = np.tril(Ld.cpu().numpy().astype(np.float64))
+	assert rel_err(Lg @ Lg.T, K) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------ RFF
+@pytest.mark.parametrize("n,d,m", [(33, 5, 64), (200, 64, 130), (129, 1, 256)])
+def test_rff(L, n, d, m):
+	rng = np.random.RandomState(n + d + m)
+	x, W, b = rng.uniform(0, 1, size=(n, d)), rng.normal(size=(m, d)) / 0.7, 2 * np.pi * rng.uniform(size=m)
+	lib = L.load()
+	out = torch.empty((n, m), dtype=torch.float64, device="cuda:0")
+	scale = np.sqrt(2.0 / m) * np.sqrt(2.5)
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(dev(x)), n, d, d, L.ptr(dev(W)), d, m, None, scale, L.ptr(out), m, L.stream_ptr()), "rff")
+	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5)) < 1e-14
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(dev(x)), n, d, d, L.ptr(dev(W)), d, m, L.ptr(dev(b)), scale, L.ptr(out), m, L.stream_ptr()), "rff")
+	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5, b=b).T) < 1e-14
+
+
+def test_rff_f32(L):
+	rng = np.random.RandomState(2)
+	n, d, m = 300, 64, 512
+	x, W = rng.uniform(0, 1, size=(n, d)).astype(np.float32), (rng.normal(size=(m, d)) / 8.0).astype(np.float32)
+	lib = L.load()
+	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(dev(x, torch.float32)), n, d, d, L.ptr(dev(W, torch.float32)), d, m, None,
+							   float(np.sqrt(2.0 / m)), L.ptr(out), m, L.stream_ptr()), "rff")
+	ref = O.rff_embed(x.astype(np.float64), W.astype(np.float64), m)
+	assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max() * 10
+
+
+def test_error_reporting(L):
+	lib = L.load()
+	rc = lib.stpy_gram(99, L.F64, None, 1, 1, None, 1, 1, 1, None, None, 1.0, 0.0, 0.0, 0, 0, None, 1, L.stream_ptr())
+	assert rc < 0 and b"null" in lib.stpy_last_error_string()
+	x = dev(np.zeros((2, 2)))
+	rc = lib.stpy_gemm_nt(7, 2, 2, 2, L.ptr(x), 2, L.ptr(x), 2, L.ptr(x), 2, 0, 0, L.stream_ptr())
+	assert rc < 0 and b"dtype" in lib.stpy_last_error_string()

@@ -1,0 +1,69 @@
+"""Scratch micro-benchmarks of the C-ABI entry points (GPU box only)."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from stpy_amd import _lib as L
+
+lib = L.load()
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=3, warm=1):
+	for _ in range(warm):
+		fn()
+	torch.cuda.synchronize()
+	ts = []
+	for _ in range(reps):
+		e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		e0.record()
+		fn()
+		e1.record()
+		torch.cuda.synchronize()
+		ts.append(e0.elapsed_time(e1) * 1e-3)
+	return min(ts), float(np.median(ts))
+
+
+def bench_gemm(n, k, tri):
+	P = torch.randn(n, k, dtype=torch.float64, device=dev)
+	C = torch.randn(n, n, dtype=torch.float64, device=dev)
+	f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, 1, tri, L.stream_ptr()), "gemm")
+	t, tm = timeit(f)
+	flops = 2.0 * n * n * k * (0.5 + 64.0 / n if tri else 1.0)
+	print("gemm_nt n=%d k=%d tri=%d: %.3f ms  %.1f TF/s (min)  median %.3f ms" % (n, k, tri, t * 1e3, flops / t / 1e12, tm * 1e3), flush=True)
+
+
+def bench_potrf(n, nb):
+	x = torch.rand(n, 16, dtype=torch.float64, device=dev) * 2 - 1
+	il = torch.full((16,), 0.25, dtype=torch.float64, device=dev)
+	K = torch.empty(n, n, dtype=torch.float64, device=dev)
+	winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device=dev)
+	work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), dtype=torch.uint8, device=dev)
+	info = torch.zeros(1, dtype=torch.int32, device=dev)
+	gram = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.stream_ptr()), "gram")
+	t, _ = timeit(gram)
+	print("gram lower n=%d: %.3f ms  %.2f TB/s" % (n, t * 1e3, n * n * 8 * 0.5 / t / 1e12), flush=True)
+	def f():
+		gram()
+		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), nb, L.ptr(info), L.stream_ptr()), "potrf")
+	t2, _ = timeit(f, reps=2)
+	tp = t2 - t
+	print("potrf n=%d nb=%d: %.3f s  %.1f TF/s  info=%d" % (n, nb, tp, n ** 3 / 3.0 / tp / 1e12, int(info.item())), flush=True)
+
+
+if __name__ == "__main__":
+	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which in ("all", "gemm"):
+		bench_gemm(8192, 512, 0)
+		bench_gemm(16384, 512, 1)
+		bench_gemm(32768, 512, 1)
+		bench_gemm(32768, 256, 1)
+		bench_gemm(32768, 1024, 1)
+	if which in ("all", "potrf"):
+		for n, nb in ((8192, 512), (16384, 512), (32768, 512), (32768, 256), (32768, 1024)):
+			bench_potrf(n, nb)
+	if which == "big":
+		bench_potrf(65536, 512)
