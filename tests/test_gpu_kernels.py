@@ -148,19 +148,20 @@ def test_gram_cols_combine_diag_lower(L):
 	colsd = torch.tensor(cols, dtype=torch.int32, device="cuda:0")
 	lib = L.load()
 	out = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
-	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(dev(inv_ls)), 1.1, 0.0, 0.0, 0, L.OUT_SET,
+	ild, il2d = dev(inv_ls), dev(np.full(d, 0.7))
+	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(ild), 1.1, 0.0, 0.0, 0, L.OUT_SET,
 						  L.ptr(out), n, L.stream_ptr()), "gram")
 	k1 = oracle_gram(0, x, x, inv_ls, 1.1, 0.0, cols)
 	assert rel_err(out.cpu().numpy(), k1) < 1e-13
 	# product with a Matern 5/2 on all columns, then diag_add on the last item
 	il2 = np.full(d, 0.7)
-	L.check(lib.stpy_gram(3, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, d, None, L.ptr(dev(il2)), 0.9, 0.0, 0.04, 0, L.OUT_MUL,
+	L.check(lib.stpy_gram(3, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, d, None, L.ptr(il2d), 0.9, 0.0, 0.04, 0, L.OUT_MUL,
 						  L.ptr(out), n, L.stream_ptr()), "gram")
 	k2 = k1 * oracle_gram(3, x, x, il2, 0.9, 0.0, None) + 0.04 * np.eye(n)
 	assert rel_err(out.cpu().numpy(), k2) < 1e-13
 	# lower_only: lower triangle identical, sum with ADD
 	out2 = torch.full((n, n), 7.0, dtype=torch.float64, device="cuda:0")
-	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(dev(inv_ls)), 1.1, 0.0, 0.5, 1, L.OUT_SET,
+	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(ild), 1.1, 0.0, 0.5, 1, L.OUT_SET,
 						  L.ptr(out2), n, L.stream_ptr()), "gram")
 	o2 = out2.cpu().numpy()
 	il = np.tril_indices(n)
@@ -178,7 +179,8 @@ def test_gram_diag_and_symmetrize(L):
 	il = dev(np.full(d, 0.5))
 	L.check(lib.stpy_gram_diag(0, L.F64, L.ptr(xd), m, d, d, None, L.ptr(il), 1.7, 0.0, L.OUT_SET, L.ptr(out), L.stream_ptr()), "diag")
 	assert np.allclose(out.cpu().numpy(), 1.7, rtol=0, atol=0)
-	L.check(lib.stpy_gram_diag(4, L.F64, L.ptr(xd), m, d, d, None, L.ptr(dev(np.ones(d))), 2.0, 0.5, L.OUT_ADD, L.ptr(out), L.stream_ptr()), "diag")
+	ones = dev(np.ones(d))
+	L.check(lib.stpy_gram_diag(4, L.F64, L.ptr(xd), m, d, d, None, L.ptr(ones), 2.0, 0.5, L.OUT_ADD, L.ptr(out), L.stream_ptr()), "diag")
 	assert rel_err(out.cpu().numpy(), 1.7 + 2.0 * np.sum(x * x, axis=1) + 0.5) < 1e-14
 	n = 200
 	A = rng.normal(size=(n, n))
@@ -254,7 +256,8 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	assert rel_err(ad.cpu().numpy(), aref) < 1e-10
 	kdiag = np.full(m, 5.0 + np.max(np.sum(Xref * Xref, axis=1)))
 	mu, sg = torch.empty(m, dtype=torch.float64, device="cuda:0"), torch.empty(m, dtype=torch.float64, device="cuda:0")
-	L.check(lib.stpy_predict(L.F64, m, n, L.ptr(Bd), n, L.ptr(zd), L.ptr(dev(kdiag)), L.ptr(mu), L.ptr(sg), 0, L.stream_ptr()), "predict")
+	kdd = dev(kdiag)
+	L.check(lib.stpy_predict(L.F64, m, n, L.ptr(Bd), n, L.ptr(zd), L.ptr(kdd), L.ptr(mu), L.ptr(sg), 0, L.stream_ptr()), "predict")
 	assert rel_err(mu.cpu().numpy(), Xref @ zref) < 1e-11
 	assert rel_err(sg.cpu().numpy(), np.sqrt(kdiag - np.sum(Xref * Xref, axis=1))) < 1e-12
 	out2 = torch.empty(2, dtype=torch.float64, device="cuda:0")
@@ -296,9 +299,10 @@ def test_rff(L, n, d, m):
 	lib = L.load()
 	out = torch.empty((n, m), dtype=torch.float64, device="cuda:0")
 	scale = np.sqrt(2.0 / m) * np.sqrt(2.5)
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(dev(x)), n, d, d, L.ptr(dev(W)), d, m, None, scale, L.ptr(out), m, L.stream_ptr()), "rff")
+	xd, Wd, bd = dev(x), dev(W), dev(b)          # keep the device buffers alive across the launches
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), m, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5)) < 1e-14
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(dev(x)), n, d, d, L.ptr(dev(W)), d, m, L.ptr(dev(b)), scale, L.ptr(out), m, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), m, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5, b=b).T) < 1e-14
 
 
@@ -308,7 +312,8 @@ def test_rff_f32(L):
 	x, W = rng.uniform(0, 1, size=(n, d)).astype(np.float32), (rng.normal(size=(m, d)) / 8.0).astype(np.float32)
 	lib = L.load()
 	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(dev(x, torch.float32)), n, d, d, L.ptr(dev(W, torch.float32)), d, m, None,
+	xd, Wd = dev(x, torch.float32), dev(W, torch.float32)
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None,
 							   float(np.sqrt(2.0 / m)), L.ptr(out), m, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x.astype(np.float64), W.astype(np.float64), m)
 	assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max() * 10
