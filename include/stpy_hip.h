@@ -124,6 +124,16 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
                    const void* W, int64_t ldw, int64_t m, const void* bias, double scale,
                    void* out, int64_t ldo, void* stream);
 
+/*
+ * Launch profiler (bench.py's live roofline numbers).  While enabled, HIP events are recorded on
+ * the launch stream around every MFMA GEMM / diagonal-block launch.  tag: 0 = trailing SYRK
+ * update of potrf, 1 = panel GEMMs of potrf, 2 = GEMMs of stpy_trsm_right_lt, 3 = 128x128
+ * diagonal-block kernel, 4 = direct stpy_gemm_nt calls.  read() returns the summed event time
+ * (ms), the summed algorithmic flops and the number of launches of that tag.
+ */
+void stpy_profile_enable(int enable);
+int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface of libstpy_hip.so (see include/stpy_hip.h).
 #include <stdarg.h>
 #include <string.h>
+#include <vector>
 
 #include "common.h"
 
@@ -24,6 +25,31 @@ int check_launch(const char* what)
 		return -1000 - (int)e;
 	}
 	return 0;
+}
+
+// ---- launch profiler -------------------------------------------------------------------------
+struct ProfRec { hipEvent_t e0, e1; double flops; int tag; };
+static std::vector<ProfRec> g_prof;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
+ProfScope::ProfScope(int tag, double flops, hipStream_t st_) : slot(-1), st(st_)
+{
+	if (!g_prof_on) return;
+	if (g_prof_used == g_prof.size()) {
+		ProfRec r;
+		if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+		g_prof.push_back(r);
+	}
+	slot = (int)g_prof_used++;
+	g_prof[slot].flops = flops;
+	g_prof[slot].tag = tag;
+	(void)hipEventRecord(g_prof[slot].e0, st);
+}
+
+ProfScope::~ProfScope()
+{
+	if (slot >= 0) (void)hipEventRecord(g_prof[slot].e1, st);
 }
 
 }  // namespace stpy
@@ -127,6 +153,7 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int6
 {
 	if (!A || !B || !C) { set_error("stpy_gemm_nt: null pointer"); return -5; }
 	hipStream_t st = (hipStream_t)stream;
+	ProfScope ps(TAG_GEMM_API, (lower_only && m == n) ? (double)m * (double)n * (double)k : 2.0 * (double)m * (double)n * (double)k, st);
 	DISPATCH(dtype,
 	         gemm_nt<double>(m, n, k, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, (double*)nullptr, 0, mode, lower_only, st),
 	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, lower_only, st));
@@ -148,6 +175,30 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, cons
 	DISPATCH(dtype,
 	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, scale, (double*)out, ldo, st),
 	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, scale, (float*)out, ldo, st));
+}
+
+/* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
+void stpy_profile_enable(int enable)
+{
+	g_prof_on = enable != 0;
+	if (g_prof_on) g_prof_used = 0;
+}
+
+int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* launches)
+{
+	double ms = 0, fl = 0;
+	int64_t cnt = 0;
+	for (size_t i = 0; i < g_prof_used; ++i) {
+		if (g_prof[i].tag != tag) continue;
+		if (hipEventSynchronize(g_prof[i].e1) != hipSuccess) { set_error("stpy_profile_read: event sync failed"); return -1; }
+		float t = 0;
+		if (hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1) != hipSuccess) { set_error("stpy_profile_read: elapsed failed"); return -1; }
+		ms += t; fl += g_prof[i].flops; ++cnt;
+	}
+	if (total_ms) *total_ms = ms;
+	if (total_flops) *total_flops = fl;
+	if (launches) *launches = cnt;
+	return 0;
 }
 
 }  // extern "C"

@@ -13,6 +13,16 @@ constexpr int IB = 128;          // inner (diagonal) block of the factorisation 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// ---- optional launch profiler (stpy_profile_*): HIP events recorded on the launch stream around
+// ---- every tagged kernel, so bench.py can report the dominant kernel's live average duration.
+enum { TAG_SYRK = 0, TAG_PANEL_GEMM = 1, TAG_TRSM_GEMM = 2, TAG_POTF2 = 3, TAG_GEMM_API = 4, TAG_COUNT = 5 };
+struct ProfScope {
+	int slot;
+	hipStream_t st;
+	ProfScope(int tag, double flops, hipStream_t st);
+	~ProfScope();
+};
+
 // ---- MFMA 16x16x4 traits: the only thing that differs between f64 and f32 is the builtin and
 // ---- the C/D row map (cdna_hip_programming.md section 3: f64 row = (lane>>4) + 4*reg,
 // ---- f32 row = 4*(lane>>4) + reg); A/B: lane l holds A[l&15][k=l>>4], B[k=l>>4][l&15].

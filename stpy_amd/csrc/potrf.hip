@@ -146,12 +146,17 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 			const int64_t cb = (n - c < IB) ? (n - c) : IB;
 			const int64_t jj = c - k;
 			if (jj > 0) {       // A[c:n, c:c+cb] -= P[c:n, 0:jj] P[c:c+cb, 0:jj]^T
+				ProfScope ps(TAG_PANEL_GEMM, 2.0 * (double)(n - c) * (double)cb * (double)jj, st);
 				rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st);
 				if (rc) return rc;
 			}
+			{
+			ProfScope ps(TAG_POTF2, (double)cb * cb * cb / 3.0, st);
 			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st);
+			}
 			if (rc) return rc;
 			if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
+				ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
 				rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
 				                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st);
 				if (rc) return rc;
@@ -159,6 +164,7 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		}
 		if (k + kb < n) {       // trailing update, lower tiles only
 			const int64_t r = k + kb;
+			ProfScope ps(TAG_SYRK, (double)(n - r) * (double)(n - r) * (double)kb, st);              // lower triangle: m^2 k
 			rc = gemm_nt<T>(n - r, n - r, kb, P + r * ldp, ldp, P + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 1, st);
 			if (rc) return rc;
 		}

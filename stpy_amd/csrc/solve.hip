@@ -21,15 +21,20 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 			const int64_t cb = (n - c < IB) ? (n - c) : IB;
 			const int64_t jj = c - k;
 			if (jj > 0) {   // B[:, c:c+cb] -= B[:, k:c] L[c:c+cb, k:c]^T
+				ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)m * (double)cb * (double)jj, st);
 				rc = gemm_nt<T>(m, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
 				if (rc) return rc;
 			}
 			// B[:, c:c+cb] <- B[:, c:c+cb] inverse(L_cc)^T   (one column tile => safe in place)
-			rc = gemm_nt<T>(m, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
+			{
+				ProfScope ps(TAG_TRSM_GEMM, (double)m * (double)cb * (double)cb, st);
+				rc = gemm_nt<T>(m, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
+			}
 			if (rc) return rc;
 		}
 		if (k + kb < n) {   // B[:, k+kb:] -= B[:, k:k+kb] L[k+kb:, k:k+kb]^T
 			const int64_t r = k + kb;
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)m * (double)(n - r) * (double)kb, st);
 			rc = gemm_nt<T>(m, n - r, kb, B + k, ldb, L + r * ldl + k, ldl, B + r, ldb, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
