@@ -132,6 +132,8 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
  * (ms), the summed algorithmic flops and the number of launches of that tag.
  */
 void stpy_profile_enable(int enable);
+/* tuning knob for A/B benchmarks: key 0 = first-round workgroup stagger of the GEMM (default 1) */
+void stpy_tune(int key, int value);
 int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* launches);
 
 #ifdef __cplusplus

@@ -94,7 +94,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, i
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
 {
 	if (nb <= 0) nb = 512;
-	return n * (int64_t)nb * (dtype == STPY_F64 ? 8 : 4);
+	return 2 * n * (int64_t)nb * (dtype == STPY_F64 ? 8 : 4);     /* two panel workspaces (look-ahead) */
 }
 
 int64_t stpy_potrf_winv_elems(int64_t n) { return ((n + IB - 1) / IB) * (int64_t)IB * IB; }
@@ -175,6 +175,12 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, cons
 	DISPATCH(dtype,
 	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, scale, (double*)out, ldo, st),
 	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, scale, (float*)out, ldo, st));
+}
+
+/* experiment knobs (benchmarks only): key 0 = gemm first-round stagger on/off */
+void stpy_tune(int key, int value)
+{
+	if (key == 0) g_gemm_stagger = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */

@@ -10,6 +10,7 @@ namespace stpy {
 
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 
+extern int g_gemm_stagger;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

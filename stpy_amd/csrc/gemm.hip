@@ -19,6 +19,7 @@
 namespace stpy {
 
 constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+int g_gemm_stagger = 1;
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
 
 template <typename T>
@@ -32,9 +33,10 @@ struct GemmArgs {
 	int nsuper;              // number of super-tiles enumerated
 	int mode;                // 0: C = AB^T   1: C -= AB^T
 	int tri;                 // 1: lower-triangular tile set (square C), super-tiles enumerated over the lower triangle
+	int stagger;             // >0: first-round workgroups in the odd wave slot of their SIMD start this many cycles late
 };
 
-template <typename T, bool GUARD>
+template <typename T, bool GUARD, bool SUB>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_nt_kernel(GemmArgs<T> p)
 {
@@ -69,8 +71,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		si = S / p.nst_n;
 		sj = S - si * p.nst_n;
 	}
-	const int ti = si * p.st_m + w / p.st_n;
-	const int tj = sj * p.st_n + w % p.st_n;
+	// (the tile index comes out of VALU arithmetic; readfirstlane tells the compiler it is uniform,
+	// so tile bases live in SGPRs and per-lane addresses stay 32-bit offsets)
+	const int ti = __builtin_amdgcn_readfirstlane(si * p.st_m + w / p.st_n);
+	const int tj = __builtin_amdgcn_readfirstlane(sj * p.st_n + w % p.st_n);
 	if (ti >= p.tiles_m || tj >= p.tiles_n) return;
 	if (p.tri && tj > ti) return;
 
@@ -105,23 +109,53 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			}
 		}
 	};
+	// SUB (C -= A B^T): accumulate (-A) B^T on top of C
 	auto lstore = [&](int buf) {
 #pragma unroll
 		for (int q = 0; q < NP; ++q) {
 			const int r = lrow + q * RPP;
-			*(vch*)(As + (buf * BM + r) * LLD + lch * CH) = ra[q];
+			*(vch*)(As + (buf * BM + r) * LLD + lch * CH) = SUB ? -ra[q] : ra[q];
 			*(vch*)(Bs + (buf * BN + r) * LLD + lch * CH) = rb[q];
 		}
 	};
 
-	v4 acc[4][4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i)
-#pragma unroll
-		for (int j = 0; j < 4; ++j) acc[i][j] = v4{0, 0, 0, 0};
+	// ---- desynchronise the two workgroups that share a CU (see the note at the launch site)
+	if (p.stagger > 0 && b < 512) {
+		const unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_REG_HW_ID[3:0] = wave slot in its SIMD
+		if (hwid & 1u) {
+			const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+			while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+		}
+	}
 
 	const int KT = (p.k + BK - 1) / BK;
 	gload(0);
+
+	// ---- accumulators: zero, or the C tile itself when subtracting (its load overlaps the first
+	// ---- operand tile's; the epilogue is then store-only)
+	// Addressing: uniform tile base (SGPRs) + one 32-bit element offset per accumulator row; the
+	// four column tiles of a row are immediate offsets, so 16 VGPRs address all 64 elements.
+	v4 acc[4][4];
+	T* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
+	const unsigned ldc32 = (unsigned)p.ldc;
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+			const int lr_c = GUARD ? min(lr, p.m - 1 - row0) : lr;
+			const T* const crow = ctile + ((unsigned)lr_c * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) {
+				T v = T(0);
+				if (SUB) {      // unconditional loads (clamped address when ragged): no per-element branches
+					if (!GUARD) v = crow[tn * 16];
+					else v = ctile[(unsigned)lr_c * ldc32 + (unsigned)min(wn * 64 + r16 + tn * 16, p.n - 1 - col0)];
+				}
+				acc[tm][tn][i] = v;
+			}
+		}
+
 	lstore(0);
 	__syncthreads();
 	int buf = 0;
@@ -131,6 +165,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		const T* bs = Bs + (buf * BN + wn * 64 + r16) * LLD + g * 4;
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
+			// keep the two halves' fragments from being live together (32 instead of 64 VGPRs)
+			if (h == 1) __builtin_amdgcn_sched_barrier(0);
 			v2 fa[4], fb[4];
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
@@ -151,20 +187,21 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	}
 
 	// ---- epilogue: reg i of tile (tm,tn) is C[row0 + wm*64 + tm*16 + crow(lane,i)][col0 + wn*64 + tn*16 + r16]
+	T* const c2tile = p.C2 ? p.C2 + (int64_t)row0 * p.ldc2 + col0 : nullptr;
+	const unsigned ldc2_32 = (unsigned)p.ldc2;
 #pragma unroll
 	for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const int row = row0 + wm * 64 + tm * 16 + MM::crow(lane, i);
+			const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+			T* const crow = ctile + ((unsigned)lr * ldc32 + (unsigned)(wn * 64 + r16));
+			T* const c2row = c2tile + ((unsigned)lr * ldc2_32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
 			for (int tn = 0; tn < 4; ++tn) {
-				const int col = col0 + wn * 64 + tn * 16 + r16;
-				if (GUARD && (row >= p.m || col >= p.n)) continue;
-				T v = acc[tm][tn][i];
-				T* cp = p.C + (int64_t)row * p.ldc + col;
-				if (p.mode == 1) v = *cp - v;
-				*cp = v;
-				if (p.C2) p.C2[(int64_t)row * p.ldc2 + col] = v;
+				if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
+				const T v = acc[tm][tn][i];
+				crow[tn * 16] = v;
+				if (c2tile) c2row[tn * 16] = v;
 			}
 		}
 }
@@ -199,13 +236,24 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.nsuper = p.tri ? p.nst_m * (p.nst_m + 1) / 2 : p.nst_m * p.nst_n;
 	const int64_t nblocks = (int64_t)((p.nsuper + 7) / 8) * 512;
 	if (nblocks > INT32_MAX) { set_error("gemm_nt: grid too large"); return -2; }
+	// Workgroups of one launch all take the same time, so the two that share a CU would reach
+	// their memory-bound prologue/epilogue together, round after round, and the MFMA pipes would
+	// idle for both.  Starting the odd wave slot half a tile late in the FIRST round only keeps the
+	// pair out of phase for the whole launch (later workgroups start when a predecessor ends).
+	// Only worth its cost (half a tile, once) when the launch runs for several rounds.
+	{
+		const int64_t real_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n;
+		const int64_t kt = (k + BK - 1) / BK;
+		p.stagger = (g_gemm_stagger && real_tiles >= 8 * 512) ? (int)(kt * 64 * 64) : 0;     // kt * 64 MFMAs * 64 cycles = half of a two-wave tile
+	}
 	constexpr int CH = 16 / sizeof(T);
 	const bool aligned = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && (lda % CH == 0) && (ldb % CH == 0) &&
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
-	if (aligned)
-		hipLaunchKernelGGL((gemm_nt_kernel<T, false>), dim3((unsigned)nblocks), dim3(NTHREADS), 0, st, p);
-	else
-		hipLaunchKernelGGL((gemm_nt_kernel<T, true>), dim3((unsigned)nblocks), dim3(NTHREADS), 0, st, p);
+	const dim3 grid((unsigned)nblocks), block(NTHREADS);
+	if (aligned && mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, false, true>), grid, block, 0, st, p);
+	else if (aligned) hipLaunchKernelGGL((gemm_nt_kernel<T, false, false>), grid, block, 0, st, p);
+	else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, true, true>), grid, block, 0, st, p);
+	else hipLaunchKernelGGL((gemm_nt_kernel<T, true, false>), grid, block, 0, st, p);
 	return check_launch("gemm_nt");
 }
 

@@ -53,7 +53,17 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 		if (row >= j) {
 			const T* si = S + row * SLD;
 			const T* sj = S + j * SLD;
-			for (int k = q; k < j; k += 4) part += si[k] * sj[k];
+			// four independent partial sums: the LDS reads of a 16-deep step are all in flight together
+			T p1 = T(0), p2 = T(0), p3 = T(0);
+			int k = q;
+			for (; k + 12 < j; k += 16) {
+				part += si[k] * sj[k];
+				p1 += si[k + 4] * sj[k + 4];
+				p2 += si[k + 8] * sj[k + 8];
+				p3 += si[k + 12] * sj[k + 12];
+			}
+			for (; k < j; k += 4) part += si[k] * sj[k];
+			part += (p1 + p2) + p3;
 		}
 		part += __shfl_xor(part, 1);
 		part += __shfl_xor(part, 2);
@@ -99,7 +109,16 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 			if (i > c) {
 				const T* li = S + i * SLD;
 				const T* wc = S + c * SLD;
-				for (int k = c + q; k < i; k += 4) part += li[k] * wc[k];
+				T p1 = T(0), p2 = T(0), p3 = T(0);
+				int k = c + q;
+				for (; k + 12 < i; k += 16) {
+					part += li[k] * wc[k];
+					p1 += li[k + 4] * wc[k + 4];
+					p2 += li[k + 8] * wc[k + 8];
+					p3 += li[k + 12] * wc[k + 12];
+				}
+				for (; k < i; k += 4) part += li[k] * wc[k];
+				part += (p1 + p2) + p3;
 			}
 			part += __shfl_xor(part, 1);
 			part += __shfl_xor(part, 2);
@@ -130,44 +149,114 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 	return check_launch("potf2_trtri");
 }
 
+// Side stream + events for the look-ahead (one set per process, created on first use; the side
+// stream has the highest priority so the small panel kernels are dispatched ahead of the queued
+// trailing-update workgroups as CU slots free up).
+struct LookAhead {
+	hipStream_t side = nullptr;
+	hipEvent_t col_ready = nullptr, panel_done = nullptr, trail_done = nullptr;
+	int device = -1;
+};
+static LookAhead g_la;
+
+static int lookahead_init()
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { set_error("potrf: hipGetDevice failed"); return -1001; }
+	if (g_la.side && g_la.device == dev) return 0;
+	int lo = 0, hi = 0;
+	(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+	if (hipStreamCreateWithPriority(&g_la.side, hipStreamNonBlocking, hi) != hipSuccess ||
+	    hipEventCreateWithFlags(&g_la.col_ready, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&g_la.panel_done, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&g_la.trail_done, hipEventDisableTiming) != hipSuccess) {
+		set_error("potrf: could not create the look-ahead stream/events");
+		return -1002;
+	}
+	g_la.device = dev;
+	return 0;
+}
+
+// Factor the nb-wide panel whose first column is k (its columns already carry every update from
+// the panels to its left), left-looking over 128-column blocks.  Writes L into A and into the
+// panel workspace P (n x nb, leading dimension nb, rows indexed globally).
+template <typename T>
+static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* winv, T* P, int64_t ldp, int32_t* info, hipStream_t st)
+{
+	int rc;
+	for (int64_t c = k; c < k + kb; c += IB) {
+		const int64_t cb = (n - c < IB) ? (n - c) : IB;
+		const int64_t jj = c - k;
+		if (jj > 0) {       // A[c:n, c:c+cb] -= P[c:n, 0:jj] P[c:c+cb, 0:jj]^T
+			ProfScope ps(TAG_PANEL_GEMM, 2.0 * (double)(n - c) * (double)cb * (double)jj, st);
+			rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st);
+			if (rc) return rc;
+		}
+		{
+			ProfScope ps(TAG_POTF2, (double)cb * cb * cb / 3.0, st);
+			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st);
+		}
+		if (rc) return rc;
+		if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
+			ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
+			rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
+			                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st);
+			if (rc) return rc;
+		}
+	}
+	return 0;
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("potrf: %s failed: %s", #x, hipGetErrorString(e_)); return -1000 - (int)e_; } } while (0)
+
+// Right-looking with one panel of look-ahead.  For panel k (already factored, in workspace Pk):
+//   main stream : update the NEXT panel's block column  A[r:n, r:r+nb] -= Pk Pk^T       (r = k + nb)
+//                 -> event col_ready
+//                 update the rest of the trailing matrix A[r+nb:n, r+nb:n] -= Pk Pk^T (lower tiles)
+//   side stream : wait col_ready; factor panel k+1 into the OTHER workspace -> event panel_done
+//   main stream : wait panel_done before using panel k+1.
+// The two regions written concurrently are disjoint (columns [r, r+nb) vs columns >= r+nb) and the
+// trailing update reads only Pk, which the side stream never touches.
 template <typename T>
 int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st)
 {
 	if (nb <= 0) nb = 512;
 	if (nb % IB != 0) { set_error("potrf: nb must be a multiple of %d", IB); return -7; }
-	hipError_t e = hipMemsetAsync(info, 0, sizeof(int32_t), st);
-	if (e != hipSuccess) { set_error("potrf: memset(info) failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
-	T* P = work;                                   // n x nb, leading dimension nb, rows indexed globally
+	HIPCHK(hipMemsetAsync(info, 0, sizeof(int32_t), st));
 	const int64_t ldp = nb;
-	int rc;
-	for (int64_t k = 0; k < n; k += nb) {
-		const int64_t kb = (n - k < nb) ? (n - k) : nb;
-		for (int64_t c = k; c < k + kb; c += IB) {
-			const int64_t cb = (n - c < IB) ? (n - c) : IB;
-			const int64_t jj = c - k;
-			if (jj > 0) {       // A[c:n, c:c+cb] -= P[c:n, 0:jj] P[c:c+cb, 0:jj]^T
-				ProfScope ps(TAG_PANEL_GEMM, 2.0 * (double)(n - c) * (double)cb * (double)jj, st);
-				rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st);
-				if (rc) return rc;
-			}
-			{
-			ProfScope ps(TAG_POTF2, (double)cb * cb * cb / 3.0, st);
-			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st);
-			}
-			if (rc) return rc;
-			if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
-				ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
-				rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
-				                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st);
-				if (rc) return rc;
-			}
-		}
-		if (k + kb < n) {       // trailing update, lower tiles only
-			const int64_t r = k + kb;
-			ProfScope ps(TAG_SYRK, (double)(n - r) * (double)(n - r) * (double)kb, st);              // lower triangle: m^2 k
-			rc = gemm_nt<T>(n - r, n - r, kb, P + r * ldp, ldp, P + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 1, st);
+	T* Pbuf[2] = {work, work + n * ldp};
+	int rc = lookahead_init();
+	if (rc) return rc;
+	hipStream_t side = g_la.side;
+
+	rc = factor_panel<T>(n, 0, (n < nb) ? n : nb, A, lda, winv, Pbuf[0], ldp, info, st);
+	if (rc) return rc;
+	int cur = 0;
+	for (int64_t k = 0; k + nb < n; k += nb) {
+		const int64_t r = k + nb;                                   // first row/column of the trailing matrix
+		const int64_t nkb = (n - r < nb) ? (n - r) : nb;            // width of the next panel
+		T* Pk = Pbuf[cur];
+		{   // next panel's block column (all rows below r)
+			ProfScope ps(TAG_SYRK, 2.0 * (double)(n - r) * (double)nkb * (double)nb - (double)nkb * (double)nkb * (double)nb, st);
+			rc = gemm_nt<T>(n - r, nkb, nb, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
+		HIPCHK(hipEventRecord(g_la.col_ready, st));
+		HIPCHK(hipStreamWaitEvent(side, g_la.col_ready, 0));
+		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(g_la.panel_done, side));
+		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
+			const int64_t r2 = r + nkb;
+			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)nb, st);      // lower triangle: m^2 k
+			rc = gemm_nt<T>(n - r2, n - r2, nb, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, st);
+			if (rc) return rc;
+		}
+		HIPCHK(hipStreamWaitEvent(st, g_la.panel_done, 0));
+		// the side stream may not start overwriting workspace `cur` (panel k+2) before this
+		// trailing update has finished reading it: it waits on the next col_ready, which is
+		// recorded on `st` after this update -- stream order gives that for free.
+		cur ^= 1;
 	}
 	return 0;
 }

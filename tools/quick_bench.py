@@ -54,8 +54,26 @@ def bench_potrf(n, nb):
 	print("potrf n=%d nb=%d: %.3f s  %.1f TF/s  info=%d" % (n, nb, tp, n ** 3 / 3.0 / tp / 1e12, int(info.item())), flush=True)
 
 
+def ab_gemm():
+	"""interleaved A/B of the first-round stagger (one process, same buffers)"""
+	for n, k in ((32768, 512), (32768, 256), (32768, 1024), (16384, 512), (49152, 512)):
+		P = torch.randn(n, k, dtype=torch.float64, device=dev)
+		C = torch.randn(n, n, dtype=torch.float64, device=dev)
+		f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, 1, 1, L.stream_ptr()), "gemm")
+		res = {0: [], 1: []}
+		for rnd in range(4):
+			for v in (0, 1):
+				lib.stpy_tune(0, v)
+				res[v].append(timeit(f, reps=2, warm=1)[0])
+		flops = float(n) * n * k
+		print("n=%d k=%d  stagger off: %.3f ms %.1f TF | on: %.3f ms %.1f TF" % (n, k, min(res[0]) * 1e3, flops / min(res[0]) / 1e12, min(res[1]) * 1e3, flops / min(res[1]) / 1e12), flush=True)
+		del P, C
+
+
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "ab":
+		ab_gemm()
 	if which in ("all", "gemm"):
 		bench_gemm(8192, 512, 0)
 		bench_gemm(16384, 512, 1)
