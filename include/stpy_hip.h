@@ -94,7 +94,8 @@ int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv
 
 /* mu[i] = <X_i, z>,  sigma[i] = sqrt(kdiag[i] - <X_i, X_i>)   (X = K* L^-T, z = L^-1 y)
  * gauss_procc.py:381, :391-395.  clamp != 0 clamps the variance at 0 before the sqrt (the
- * reference does not clamp).  mu or sigma may be NULL. */
+ * reference does not clamp).  clamp == 2: sigma[i] receives the raw <X_i, X_i> instead (partial
+ * sums of a column-sharded X, reduced across ranks by the caller).  mu or sigma may be NULL. */
 int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, const void* z,
                  const void* kdiag, void* mu, void* sigma, int clamp, void* stream);
 
@@ -109,6 +110,17 @@ int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const voi
 int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k,
                  const void* A, int64_t lda, const void* B, int64_t ldb,
                  void* C, int64_t ldc, int mode, int lower_only, void* stream);
+
+/*
+ * The same contraction on a window of a rank's LOCAL matrix under a 2-D block-cyclic distribution
+ * (multi-GPU trailing update): distribution block nb_dist (multiple of 128), process grid pr x pc,
+ * this rank (myr, myc); the window starts at local block (i0, j0).  A 128x128 tile in local block
+ * (bi, bj) belongs to global block (I, J) = (bi*pr + myr, bj*pc + myc) and is skipped when I < J.
+ */
+int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k,
+                    const void* A, int64_t lda, const void* B, int64_t ldb,
+                    void* C, int64_t ldc, int mode,
+                    int nb_dist, int pr, int pc, int myr, int myc, int i0, int j0, void* stream);
 
 /* mirror the lower triangle into the upper one (n x n) -- materialises .K after a lower-only Gram */
 int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stream);

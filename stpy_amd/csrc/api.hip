@@ -132,7 +132,7 @@ int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv
 int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, const void* z, const void* kdiag,
                  void* mu, void* sigma, int clamp, void* stream)
 {
-	if (!X || !z || (sigma && !kdiag)) { set_error("stpy_predict: null pointer"); return -4; }
+	if (!X || !z || (sigma && !kdiag && clamp != 2)) { set_error("stpy_predict: null pointer"); return -4; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         predict<double>(m, n, (const double*)X, ldx, (const double*)z, (const double*)kdiag, (double*)mu, (double*)sigma, clamp, st),
@@ -157,6 +157,19 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int6
 	DISPATCH(dtype,
 	         gemm_nt<double>(m, n, k, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, (double*)nullptr, 0, mode, lower_only, st),
 	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, lower_only, st));
+}
+
+int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    void* C, int64_t ldc, int mode, int nb_dist, int pr, int pc, int myr, int myc, int i0, int j0, void* stream)
+{
+	if (!A || !B || !C) { set_error("stpy_gemm_nt_bc: null pointer"); return -5; }
+	if (pr <= 0 || pc <= 0 || myr < 0 || myr >= pr || myc < 0 || myc >= pc || i0 < 0 || j0 < 0) { set_error("stpy_gemm_nt_bc: bad process-grid arguments"); return -13; }
+	hipStream_t st = (hipStream_t)stream;
+	BlockCyclic bc{nb_dist, pr, pc, myr, myc, i0, j0};
+	ProfScope ps(TAG_GEMM_API, 2.0 * (double)m * (double)n * (double)k, st);
+	DISPATCH(dtype,
+	         gemm_nt<double>(m, n, k, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, (double*)nullptr, 0, mode, 0, st, &bc),
+	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, 0, st, &bc));
 }
 
 int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stream)

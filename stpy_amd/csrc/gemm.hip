@@ -34,6 +34,11 @@ struct GemmArgs {
 	int mode;                // 0: C = AB^T   1: C -= AB^T
 	int tri;                 // 1: lower-triangular tile set (square C), super-tiles enumerated over the lower triangle
 	int stagger;             // >0: first-round workgroups in the odd wave slot of their SIMD start this many cycles late
+	// block-cyclic "staircase" (multi-GPU local trailing update): C is a window of a rank's local
+	// matrix; tile (ti,tj) lies in distribution block (ti/bc_nbt + bc_i0, tj/bc_nbt + bc_j0) of
+	// the local matrix = global block (I, J) = (.. * bc_pr + bc_myr, .. * bc_pc + bc_myc); tiles
+	// with I < J (strictly above the global diagonal) are skipped.  bc_nbt == 0: off.
+	int bc_nbt, bc_pr, bc_pc, bc_myr, bc_myc, bc_i0, bc_j0;
 };
 
 template <typename T, bool GUARD, bool SUB>
@@ -77,6 +82,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	const int tj = __builtin_amdgcn_readfirstlane(sj * p.st_n + w % p.st_n);
 	if (ti >= p.tiles_m || tj >= p.tiles_n) return;
 	if (p.tri && tj > ti) return;
+	if (p.bc_nbt > 0) {
+		const int I = (ti / p.bc_nbt + p.bc_i0) * p.bc_pr + p.bc_myr;
+		const int J = (tj / p.bc_nbt + p.bc_j0) * p.bc_pc + p.bc_myc;
+		if (I < J) return;
+	}
 
 	const int row0 = ti * BM, col0 = tj * BN;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,7 +218,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
-            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st)
+            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (k <= 0) {
@@ -223,7 +233,12 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.tiles_m = (int)((m + BM - 1) / BM);
 	p.tiles_n = (int)((n + BN - 1) / BN);
 	p.mode = mode;
-	p.tri = (lower_only && m == n) ? 1 : 0;
+	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
+	p.bc_nbt = 0; p.bc_pr = p.bc_pc = 1; p.bc_myr = p.bc_myc = p.bc_i0 = p.bc_j0 = 0;
+	if (bc) {
+		if (bc->nb_dist <= 0 || bc->nb_dist % BM != 0) { set_error("gemm_nt: block-cyclic block must be a positive multiple of %d", BM); return -13; }
+		p.bc_nbt = bc->nb_dist / BM; p.bc_pr = bc->pr; p.bc_pc = bc->pc; p.bc_myr = bc->myr; p.bc_myc = bc->myc; p.bc_i0 = bc->i0; p.bc_j0 = bc->j0;
+	}
 	if (p.tri) {
 		p.st_m = ST; p.st_n = ST;
 	} else {
@@ -257,7 +272,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	return check_launch("gemm_nt");
 }
 
-template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t);
-template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t);
+template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*);
+template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*);
 
 }  // namespace stpy

@@ -174,9 +174,13 @@ void predict_kernel(const T* __restrict__ X, int64_t ldx, int n, const T* __rest
 		s2 = r2[0] + r2[1] + r2[2] + r2[3];
 		if (mu) mu[i] = s1;
 		if (sigma) {
-			T var = kdiag[i] - s2;
-			if (clamp && var < T(0)) var = T(0);
-			sigma[i] = sqrt(var);
+			if (clamp == 2) {           // raw partial sum of squares (multi-GPU: reduced across ranks first)
+				sigma[i] = s2;
+			} else {
+				T var = kdiag[i] - s2;
+				if (clamp && var < T(0)) var = T(0);
+				sigma[i] = sqrt(var);
+			}
 		}
 	}
 }

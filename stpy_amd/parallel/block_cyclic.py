@@ -1,0 +1,385 @@
+"""
+2-D block-cyclic GP fit / predict across the GPUs of one node (BASELINE config 4; north_star:
+"N x N Gram matrix sharded 2D block-cyclic ... panel broadcast ... on RCCL over xGMI").
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL), process grid P = P_r x P_c,
+distribution block NB (a multiple of 128).  Global block (I, J) of K = k(x,x) + s^2 I lives on
+rank (I mod P_r, J mod P_c) at local block (I div P_r, J div P_c) of that rank's local matrix
+``Aloc`` (row-major, contiguous).  x, y and xtest are replicated (N*d*8 B = 33 MB at C4).
+
+fit (right-looking Cholesky, one block column K per step)
+  1. rank (K%P_r, K%P_c) factors the NB x NB diagonal block with the single-GPU ``stpy_potrf``
+     and broadcasts L_KK + its inverse 128-blocks down its process COLUMN;
+  2. the ranks of that process column solve their part of the panel, L_IK = A_IK L_KK^-T
+     (``stpy_trsm_right_lt``, in place in Aloc);
+  3. panel broadcast along process ROWS: every rank obtains L_IK for its own local block rows I;
+  4. "transposed" exchange inside each process column: rank (r', c) owns, after step 3, the blocks
+     L_JK with J%P_r == r'; the ones with J%P_c == c are broadcast down the column so every rank
+     has L_JK for its own local block columns J;
+  5. local trailing update  Aloc[I>K, J>K] -= Prow Pcol^T  by ONE launch of the MFMA GEMM with the
+     block-cyclic staircase predicate (``stpy_gemm_nt_bc``) -- no communication.
+  Right-looking Cholesky needs no reduction of the trailing update; the only collectives are the
+  three broadcasts per step.  Volume per rank and step: (rows/P_r + cols/P_c) * NB * 8 B.
+
+predict  (X = K* L^-T, rows = test points, column blocks distributed like L's and replicated down
+each process column)  left-looking, so only M x NB blocks move, never L:
+  X_K = (K*_K - sum_{J<K} X_J L_KJ^T) L_KK^-T :  every rank of process row K%P_r forms the partial
+  sum over ITS local block columns J < K with one GEMM (the operands are contiguous in local
+  storage), the partials are summed onto the diagonal owner (reduce along the process row), the
+  owner finishes the block and broadcasts it down its process column.  mu = X z and
+  sigma^2 = kdiag - rowsum(X o X) are all-reduced partial sums; z = L^-1 y is the same solve with
+  a single right-hand side.
+
+All arithmetic goes through a ``LocalOps`` object.  The product backend is ``HipLocalOps`` (the C
+ABI of libstpy_hip; raises without a GPU).  Tests inject a CPU backend from ``tests/`` to exercise
+the index arithmetic and the collectives on gloo; nothing here imports the oracle.
+
+Round-1 status: correct-by-construction, exercised on gloo with 2 and 4 CPU ranks; no look-ahead
+yet (communication is not overlapped with the trailing update), single-GPU hardware only in the
+authoring loop.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from ..kernels import KernelFunction
+
+IB = 128
+
+
+def default_grid(world):
+	"""P_r x P_c with P_r the largest divisor of P not above sqrt(P): 1x1, 1x2, 2x2, 2x4."""
+	pr = 1
+	for c in range(1, int(math.isqrt(world)) + 1):
+		if world % c == 0:
+			pr = c
+	return pr, world // pr
+
+
+class HipLocalOps:
+	"""Local tile arithmetic on this process's GPU through libstpy_hip.  No CPU path."""
+
+	def __init__(self, dtype=torch.float64, nb=0):
+		self.lib = _lib.load()
+		self.device = _lib.device()
+		self.dtype = dtype
+		self.code = _lib.dtype_code(dtype)
+		self.nb = nb
+
+	def empty(self, *shape):
+		return torch.empty(shape, dtype=self.dtype, device=self.device)
+
+	def zeros(self, *shape):
+		return torch.zeros(shape, dtype=self.dtype, device=self.device)
+
+	def to_device(self, t):
+		return _lib.to_device(t, self.dtype)
+
+	def gram(self, kernel_object, xa, xb, out, kwargs=None):
+		"""out[j, i] = k(xb_j, xa_i); out may be a strided 2-D view."""
+		kernel_object._kernel_into(xa, xb, out, kwargs)
+
+	def kdiag(self, kernel_object, xt):
+		out = self.empty(xt.shape[0])
+		kernel_object._diag_into(xt, out)
+		return out
+
+	def potrf(self, A):
+		"""In-place Cholesky of the (strided) square view A; returns (winv, info_tensor)."""
+		n = A.shape[0]
+		winv = self.empty(int(self.lib.stpy_potrf_winv_elems(n)))
+		work = torch.empty((int(self.lib.stpy_potrf_workspace_bytes(self.code, n, self.nb)),), dtype=torch.uint8, device=self.device)
+		info = torch.zeros((1,), dtype=torch.int32, device=self.device)
+		_lib.check(self.lib.stpy_potrf(self.code, n, _lib.ptr(A), A.stride(0), _lib.ptr(winv), _lib.ptr(work), self.nb,
+									   _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
+		return winv, info
+
+	def trsm_right_lt(self, B, L, winv):
+		"""B <- B L^-T in place; B: (m, n) strided view, L: (n, n) view, winv from potrf(L)."""
+		m, n = B.shape
+		if m == 0:
+			return
+		_lib.check(self.lib.stpy_trsm_right_lt(self.code, m, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(B), B.stride(0),
+											   self.nb, _lib.stream_ptr()), "stpy_trsm_right_lt")
+
+	def gemm_nt(self, A, B, C, mode, bc=None):
+		"""C (mode 0: =, 1: -=) A B^T.  bc = (nb_dist, pr, pc, myr, myc, i0, j0) enables the staircase."""
+		m, k = A.shape
+		n = B.shape[0]
+		if m == 0 or n == 0 or k == 0:
+			return
+		if bc is None:
+			rc = self.lib.stpy_gemm_nt(self.code, m, n, k, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0),
+									   mode, 0, _lib.stream_ptr())
+		else:
+			rc = self.lib.stpy_gemm_nt_bc(self.code, m, n, k, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0),
+										  mode, *[int(v) for v in bc], _lib.stream_ptr())
+		_lib.check(rc, "stpy_gemm_nt")
+
+	def row_sums(self, X, z):
+		"""(sum_k X[i,k] z[k], sum_k X[i,k]^2) for every row of the strided view X."""
+		m, n = X.shape
+		s1, s2 = self.empty(m), self.empty(m)
+		if n == 0:
+			return s1.zero_(), s2.zero_()
+		_lib.check(self.lib.stpy_predict(self.code, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(z), None, _lib.ptr(s1), _lib.ptr(s2), 2,
+										 _lib.stream_ptr()), "stpy_predict")
+		return s1, s2
+
+	def logdet(self, L):
+		"""sum_i log L_ii of the (strided) factor block L."""
+		out2 = self.empty(2)
+		_lib.check(self.lib.stpy_logdet_quad(self.code, L.shape[0], _lib.ptr(L), L.stride(0), None, _lib.ptr(out2), _lib.stream_ptr()), "stpy_logdet_quad")
+		return out2[0]
+
+
+class DistributedGaussianProcess:
+	"""``GaussianProcess`` on a P_r x P_c process grid: same constructor, ``fit_gp`` / ``mean_std`` /
+	``log_marginal`` (default hyper-parameters only), results replicated on every rank."""
+
+	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", nu=1.5, kernel=None, d=1,
+				 grid=None, nb_dist=512, ops=None, group=None):
+		self.s = s
+		self.d = d
+		self.kernel_object = kernel if kernel is not None else KernelFunction(kernel_name=kernel_name, gamma=gamma, nu=nu, kappa=kappa, d=d)
+		self.ops = ops if ops is not None else HipLocalOps()
+		if not dist.is_initialized():
+			raise RuntimeError("DistributedGaussianProcess needs torch.distributed to be initialised (one process per GPU)")
+		self.world = dist.get_world_size()
+		self.rank = dist.get_rank()
+		self.Pr, self.Pc = grid if grid is not None else default_grid(self.world)
+		if self.Pr * self.Pc != self.world:
+			raise ValueError("process grid %dx%d does not match world size %d" % (self.Pr, self.Pc, self.world))
+		if nb_dist % IB != 0:
+			raise ValueError("nb_dist must be a multiple of %d" % IB)
+		self.NB = nb_dist
+		self.nb = 0
+		self.myr, self.myc = self.rank // self.Pc, self.rank % self.Pc      # row-major rank -> (row, col)
+		# sub-communicators: every rank creates every group, in the same order
+		self.row_groups = [dist.new_group([r * self.Pc + c for c in range(self.Pc)]) for r in range(self.Pr)]
+		self.col_groups = [dist.new_group([r * self.Pc + c for r in range(self.Pr)]) for c in range(self.Pc)]
+		self.fitted = False
+		self.clamp_variance = False
+		self.max_size = 10000
+
+	# ------------------------------------------------------------------ index arithmetic
+	def _rank_of(self, r, c):
+		return r * self.Pc + c
+
+	def _first_local_above(self, K, my, P):
+		"""index of the first local block (along one axis) whose global index exceeds K"""
+		return 0 if K < my else (K - my) // P + 1
+
+	def _count_local_below(self, K, my, P):
+		"""number of local blocks (along one axis) whose global index is < K"""
+		return 0 if K <= my else (K - my + P - 1) // P
+
+	# collectives: RCCL on device tensors; under gloo (debug / single-GPU rehearsal with several
+	# ranks sharing one card) device tensors are staged through the host
+	def _staged(self, t):
+		return t.is_cuda and dist.get_backend() == "gloo"
+
+	def _bcast(self, t, src, group, size):
+		if size <= 1:
+			return
+		if self._staged(t):
+			h = t.cpu()
+			dist.broadcast(h, src=src, group=group)
+			t.copy_(h)
+		else:
+			dist.broadcast(t, src=src, group=group)
+
+	def _reduce_sum(self, t, dst, group):
+		if self._staged(t):
+			h = t.cpu()
+			dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
+			t.copy_(h)
+		else:
+			dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+
+	def _allreduce(self, t, op):
+		if self._staged(t):
+			h = t.cpu()
+			dist.all_reduce(h, op=op)
+			t.copy_(h)
+		else:
+			dist.all_reduce(t, op=op)
+
+	# ------------------------------------------------------------------ fit
+	def fit_gp(self, x, y):
+		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
+		xd = ops.to_device(x)
+		yd = ops.to_device(y).reshape(-1)
+		n = xd.shape[0]
+		self.n = n
+		self.x, self.y = x, y
+		self._xd = xd
+		nblk = (n + NB - 1) // NB
+		self.nblk = nblk
+		nr = (nblk - myr + Pr - 1) // Pr if nblk > myr else 0         # local block rows / cols
+		nc = (nblk - myc + Pc - 1) // Pc if nblk > myc else 0
+		self.nr, self.nc = nr, nc
+
+		# ---- local Gram fill: one launch over (local row points) x (local col points)
+		def global_index(nloc, my, P):
+			idx = (torch.arange(nloc * NB, device=xd.device) // NB * P + my) * NB + torch.arange(nloc * NB, device=xd.device) % NB
+			return idx
+		gr = global_index(nr, myr, Pr)
+		gc = global_index(nc, myc, Pc)
+		self._gc = gc
+		Aloc = ops.empty(max(nr * NB, 1), max(nc * NB, 1))
+		if nr > 0 and nc > 0:
+			xr = xd[gr.clamp(max=n - 1)].contiguous()
+			xc = xd[gc.clamp(max=n - 1)].contiguous()
+			ops.gram(self.kernel_object, xc, xr, Aloc)
+			# padding (global index >= n): identity block; noise s^2 on the global diagonal
+			if int(gr[-1]) >= n:
+				Aloc[gr >= n, :] = 0
+			if int(gc[-1]) >= n:
+				Aloc[:, gc >= n] = 0
+			s2 = float(self.s) ** 2
+			for i in range(nr):
+				I = i * Pr + myr
+				if I % Pc == myc:
+					j = I // Pc
+					dblk = Aloc[i * NB:(i + 1) * NB, j * NB:(j + 1) * NB].diagonal()
+					gdiag = I * NB + torch.arange(NB, device=xd.device)
+					dblk.add_(torch.where(gdiag < n, torch.full_like(dblk, s2), torch.ones_like(dblk)))
+		self._Aloc = Aloc
+		self._winv = {}
+		bad = torch.zeros((1,), dtype=torch.int32, device=xd.device)
+
+		for K in range(nblk):
+			kr, kc, lkr, lkc = K % Pr, K % Pc, K // Pr, K // Pc
+			i0 = self._first_local_above(K, myr, Pr)
+			j0 = self._first_local_above(K, myc, Pc)
+			rows_below, cols_right = (nr - i0) * NB, (nc - j0) * NB
+			prow = ops.empty(max(rows_below, 0), NB)
+			if myc == kc:
+				winv_elems = (NB // IB) * IB * IB
+				dpack = ops.empty(NB * NB + winv_elems)          # [L_KK | inverse 128-blocks of L_KK]
+				if myr == kr:
+					D = Aloc[lkr * NB:(lkr + 1) * NB, lkc * NB:(lkc + 1) * NB]
+					winv, info = ops.potrf(D)
+					bad = torch.maximum(bad, torch.where(info > 0, info + K * NB, info))
+					dpack[:NB * NB].copy_(D.reshape(-1))
+					dpack[NB * NB:].copy_(winv)
+				self._bcast(dpack, self._rank_of(kr, kc), self.col_groups[kc], Pr)
+				Lkk = dpack[:NB * NB].reshape(NB, NB)
+				wkk = dpack[NB * NB:]
+				self._winv[K] = (Lkk, wkk)
+				if rows_below > 0:
+					panel = Aloc[i0 * NB:, lkc * NB:(lkc + 1) * NB]
+					ops.trsm_right_lt(panel, Lkk, wkk)
+					prow.copy_(panel)
+			if rows_below > 0:
+				self._bcast(prow, self._rank_of(myr, kc), self.row_groups[myr], Pc)
+			# column operand: L_JK for this rank's local block columns J > K
+			pcol = ops.empty(max(cols_right, 0), NB)
+			for rp in range(Pr):
+				Js = [J for J in range(K + 1, nblk) if J % Pc == myc and J % Pr == rp]
+				if not Js:
+					continue
+				i0p = self._first_local_above(K, rp, Pr)
+				if myr == rp:
+					sel = torch.tensor([J // Pr - i0p for J in Js], device=xd.device)
+					buf = prow.reshape(-1, NB, NB).index_select(0, sel).reshape(-1, NB)
+				else:
+					buf = ops.empty(len(Js) * NB, NB)
+				self._bcast(buf, self._rank_of(rp, myc), self.col_groups[myc], Pr)
+				dst = torch.tensor([J // Pc - j0 for J in Js], device=xd.device)
+				pcol.reshape(-1, NB, NB).index_copy_(0, dst, buf.reshape(-1, NB, NB))
+			if rows_below > 0 and cols_right > 0:
+				ops.gemm_nt(prow, pcol, Aloc[i0 * NB:, j0 * NB:], 1, bc=(NB, Pr, Pc, myr, myc, i0, j0))
+
+		self._allreduce(bad, dist.ReduceOp.MAX)
+		if int(bad.item()) != 0:
+			raise torch.linalg.LinAlgError("distributed potrf: the leading minor of order %d is not positive definite" % int(bad.item()))
+		# z = L^-1 y through the same left-looking solve with one right-hand side
+		ypad = ops.zeros(1, nblk * NB)
+		ypad[0, :n] = yd
+		self._zloc = self._solve_rows(ypad, None)
+		self.fitted = True
+		return None
+
+	fit = fit_gp
+
+	# ------------------------------------------------------------------ X = B L^-T, left-looking, column blocks distributed
+	def _solve_rows(self, rhs_full, xtest):
+		"""
+		rhs rows against L.  Either ``rhs_full`` (m x Npad, replicated; used for y) or ``xtest``
+		(m x d): then block K of the right-hand side, k(x_K, xtest), is formed by the diagonal owner.
+		Returns this rank's column blocks of X: (m, nc*NB).
+		"""
+		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
+		Aloc, n = self._Aloc, self.n
+		m = rhs_full.shape[0] if rhs_full is not None else xtest.shape[0]
+		Xloc = ops.zeros(m, max(self.nc * NB, 1))
+		for K in range(self.nblk):
+			kr, kc, lkr, lkc = K % Pr, K % Pc, K // Pr, K // Pc
+			if myr == kr:
+				jc = self._count_local_below(K, myc, Pc)
+				S = ops.zeros(m, NB)
+				if jc > 0:
+					ops.gemm_nt(Xloc[:, :jc * NB], Aloc[lkr * NB:(lkr + 1) * NB, :jc * NB], S, 0)
+				if Pc > 1:
+					self._reduce_sum(S, self._rank_of(kr, kc), self.row_groups[kr])
+			if myc == kc:
+				XK = ops.empty(m, NB)
+				if myr == kr:
+					if rhs_full is not None:
+						XK.copy_(rhs_full[:, K * NB:(K + 1) * NB])
+					else:
+						gk = (K * NB + torch.arange(NB, device=Xloc.device))
+						xk = self._xd[gk.clamp(max=n - 1)].contiguous()
+						ops.gram(self.kernel_object, xk, xtest, XK)          # XK[t, i] = k(xtest_t, x_{K,i})
+						if (K + 1) * NB > n:
+							XK[:, gk >= n] = 0
+					XK.sub_(S)
+					Lkk, wkk = self._winv[K]
+					ops.trsm_right_lt(XK, Lkk, wkk)
+				self._bcast(XK, self._rank_of(kr, kc), self.col_groups[kc], Pr)
+				Xloc[:, lkc * NB:(lkc + 1) * NB] = XK
+		return Xloc
+
+	# ------------------------------------------------------------------ predict
+	def mean_std(self, xtest, full=False, reuse=False):
+		if full:
+			raise NotImplementedError("full covariance is not provided on the distributed path")
+		if not self.fitted:
+			raise RuntimeError("fit_gp first")
+		ops = self.ops
+		xt = ops.to_device(xtest)
+		Xloc = self._solve_rows(None, xt)
+		s1, s2 = ops.row_sums(Xloc[:, :self.nc * self.NB], self._zloc.reshape(-1))
+		red = torch.stack([s1, s2])
+		self._allreduce(red, dist.ReduceOp.SUM)
+		red /= self.Pr                                  # every process row holds a replica of its columns
+		kd = ops.kdiag(self.kernel_object, xt)
+		var = kd - red[1]
+		if self.clamp_variance:
+			var = var.clamp(min=0)
+		return (_lib.like_input(red[0].reshape(-1, 1), xtest), _lib.like_input(torch.sqrt(var).reshape(-1, 1), xtest))
+
+	mean_var = mean_std
+
+	def log_marginal(self, kernel=None, X=None, weight=1.0):
+		"""1/2 z^T z + 1/2 * weight * 2 sum log L_ii for the fitted hyper-parameters (estimator.py:32-40)."""
+		if X:
+			raise NotImplementedError("hyper-parameter overrides are not provided on the distributed path")
+		ops = self.ops
+		acc = ops.zeros(2)
+		for K in range(self.nblk):
+			if K % self.Pr == self.myr and K % self.Pc == self.myc:
+				Lkk, _ = self._winv[K]
+				acc[0] += ops.logdet(Lkk)
+		if self.myr == 0 and self.nc > 0:
+			z = self._zloc[:, :self.nc * self.NB]
+			acc[1] = ops.row_sums(z, z.reshape(-1))[1][0]
+		self._allreduce(acc, dist.ReduceOp.SUM)
+		val = 0.5 * acc[1] + 0.5 * float(weight) * 2.0 * acc[0]
+		return _lib.like_input(val.reshape(1, 1), self.x)
