@@ -194,6 +194,7 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, cons
 void stpy_tune(int key, int value)
 {
 	if (key == 0) g_gemm_stagger = value;
+	if (key == 1) g_gemm_exp = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */

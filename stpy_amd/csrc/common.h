@@ -11,6 +11,7 @@ namespace stpy {
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 
 extern int g_gemm_stagger;
+extern int g_gemm_exp;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

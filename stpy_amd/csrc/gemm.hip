@@ -10,6 +10,15 @@
 // tile map: 8x8 super-tiles, one super-tile per XCD at a time, so the 8+8 operand strips a
 // super-tile needs are served from that XCD's 4 MiB L2 instead of HBM.
 //
+// Staging: the aligned fp64 path moves operand tiles HBM/L2 -> LDS with LDS-DMA
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write instructions -- measured: the 8 ds_write_b128
+// per wave and K tile of a register-staged loop cost 8 % of the kernel).  An LDS-DMA wave-instruction
+// writes 1 KiB linearly (8 tile rows of 128 B), so rows cannot be padded; bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE address and on
+// the read (guide rule 21): 16-byte chunk c of tile row r is stored at chunk c ^ f(r),
+// f(r) = ((r>>1)&3)<<1 | (r>>3)&1  -- conflict-free for all four 16-lane groups of ds_read_b128.
+// Ragged shapes and fp32 keep the register-staged path (padded rows).
+//
 // Lane/k mapping: MFMA lane l feeds A[row = l&15][k-slot = l>>4].  The sum over k is order
 // independent, so lane group g = l>>4 takes the four *consecutive* k values 4g..4g+3 of a 16-deep
 // K tile (two 16-byte LDS reads for f64) and MFMA number s of the tile uses element s of every
@@ -19,7 +28,8 @@
 namespace stpy {
 
 constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
-int g_gemm_stagger = 1;
+int g_gemm_stagger = 0;
+int g_gemm_exp = 0;        // timing experiments only (results are wrong when != 0)
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
 
 template <typename T>
@@ -39,6 +49,7 @@ struct GemmArgs {
 	// the local matrix = global block (I, J) = (.. * bc_pr + bc_myr, .. * bc_pc + bc_myc); tiles
 	// with I < J (strictly above the global diagonal) are skipped.  bc_nbt == 0: off.
 	int bc_nbt, bc_pr, bc_pc, bc_myr, bc_myc, bc_i0, bc_j0;
+	int exp;                 // timing experiments (0 in production)
 };
 
 template <typename T, bool GUARD, bool SUB>
@@ -55,10 +66,12 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	constexpr int PAD = 16 / sizeof(T);       // one 16-byte chunk of padding per LDS row
 	constexpr int LLD = BK + PAD;
 	typedef T vch __attribute__((ext_vector_type(CH)));
+	constexpr bool DMA = !GUARD && sizeof(T) == 8;      // LDS-DMA staging (unpadded, swizzled rows)
+	constexpr int RLD = DMA ? BK : LLD;                 // LDS row stride actually used
 
 	__shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LLD];
-	T* As = smem;                         // [2][BM][LLD]
-	T* Bs = smem + 2 * BM * LLD;          // [2][BN][LLD]
+	T* As = smem;                         // [2][BM][RLD]
+	T* Bs = smem + 2 * BM * RLD;          // [2][BN][RLD]
 
 	// ---- block -> tile.  Blocks b, b+8, b+16.. share an XCD (round-robin dispatch; speed only):
 	// ---- super-tile S = (b % 8) + 8 * (b / 512), tile within it = (b / 8) % 64.
@@ -124,8 +137,36 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 		for (int q = 0; q < NP; ++q) {
 			const int r = lrow + q * RPP;
-			*(vch*)(As + (buf * BM + r) * LLD + lch * CH) = SUB ? -ra[q] : ra[q];
+			*(vch*)(As + (buf * BM + r) * LLD + lch * CH) = (SUB && !DMA) ? -ra[q] : ra[q];
 			*(vch*)(Bs + (buf * BN + r) * LLD + lch * CH) = rb[q];
+		}
+	};
+
+	// ---- LDS-DMA staging: wave w moves tile rows [32w, 32w+32) of A and of B, 8 rows (1 KiB) per
+	// ---- instruction; lane -> (row = lane>>3, physical chunk = lane&7), source chunk = phys ^ f(row)
+	const T* dma_a[4];
+	const T* dma_b[4];
+	if (DMA) {
+		const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int r = wv * 32 + i * 8 + (lane >> 3);
+			const int f = (((r >> 1) & 3) << 1) | ((r >> 3) & 1);
+			const int c = (lane & 7) ^ f;
+			dma_a[i] = p.A + (int64_t)(row0 + r) * p.lda + c * 2;
+			dma_b[i] = p.B + (int64_t)(col0 + r) * p.ldb + c * 2;
+		}
+	}
+	auto dma_issue = [&](int buf, int k0) {
+		const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			T* la = As + (buf * BM + wv * 32 + i * 8) * BK;
+			T* lb = Bs + (buf * BN + wv * 32 + i * 8) * BK;
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_a[i] + k0),
+			                                 (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_b[i] + k0),
+			                                 (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
 		}
 	};
 
@@ -139,7 +180,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	}
 
 	const int KT = (p.k + BK - 1) / BK;
-	gload(0);
+	if (DMA) dma_issue(0, 0);
+	else gload(0);
 
 	// ---- accumulators: zero, or the C tile itself when subtracting (its load overlaps the first
 	// ---- operand tile's; the epilogue is then store-only)
@@ -162,26 +204,31 @@ void gemm_nt_kernel(GemmArgs<T> p)
 					if (!GUARD) v = crow[tn * 16];
 					else v = ctile[(unsigned)lr_c * ldc32 + (unsigned)min(wn * 64 + r16 + tn * 16, p.n - 1 - col0)];
 				}
-				acc[tm][tn][i] = v;
+				acc[tm][tn][i] = (SUB && DMA) ? -v : v;       // DMA path: accumulate +A B^T on -C, negate back at the store
 			}
 		}
 
-	lstore(0);
-	__syncthreads();
+	if (!DMA) lstore(0);
+	__syncthreads();            // (with LDS-DMA in flight hipcc's barrier drains vmcnt(0) first: the tile has landed)
+	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);     // read-side swizzle of this lane's rows (row & 15 == r16)
 	int buf = 0;
 	for (int kt = 0; kt < KT; ++kt) {
-		if (kt + 1 < KT) gload((kt + 1) * BK);
-		const T* as = As + (buf * BM + wm * 64 + r16) * LLD + g * 4;
-		const T* bs = Bs + (buf * BN + wn * 64 + r16) * LLD + g * 4;
+		if (kt + 1 < KT && !(p.exp & 1)) {
+			if (DMA) dma_issue(buf ^ 1, (kt + 1) * BK);
+			else gload((kt + 1) * BK);
+		}
+		const T* as = As + (buf * BM + wm * 64 + r16) * RLD + (DMA ? 0 : g * 4);
+		const T* bs = Bs + (buf * BN + wn * 64 + r16) * RLD + (DMA ? 0 : g * 4);
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			// keep the two halves' fragments from being live together (32 instead of 64 VGPRs)
 			if (h == 1) __builtin_amdgcn_sched_barrier(0);
 			v2 fa[4], fb[4];
+			const int hoff = DMA ? (((2 * g + h) ^ fsw) * 2) : h * 2;
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
-				fa[t] = *(const v2*)(as + t * 16 * LLD + h * 2);
-				fb[t] = *(const v2*)(bs + t * 16 * LLD + h * 2);
+				fa[t] = *(const v2*)(as + t * 16 * RLD + hoff);
+				fb[t] = *(const v2*)(bs + t * 16 * RLD + hoff);
 			}
 #pragma unroll
 			for (int s = 0; s < 2; ++s)
@@ -191,13 +238,12 @@ void gemm_nt_kernel(GemmArgs<T> p)
 					for (int tn = 0; tn < 4; ++tn)
 						acc[tm][tn] = MM::mma(fa[tm][s], fb[tn][s], acc[tm][tn]);
 		}
-		if (kt + 1 < KT) lstore(buf ^ 1);
-		__syncthreads();
-		buf ^= 1;
+		if (!DMA && kt + 1 < KT && !(p.exp & 2)) lstore(buf ^ 1);
+		if (!(p.exp & 4)) __syncthreads();
+		if (!(p.exp & 8)) buf ^= 1;
 	}
 
 	// ---- epilogue: reg i of tile (tm,tn) is C[row0 + wm*64 + tm*16 + crow(lane,i)][col0 + wn*64 + tn*16 + r16]
-	T* const c2tile = p.C2 ? p.C2 + (int64_t)row0 * p.ldc2 + col0 : nullptr;
 	const unsigned ldc2_32 = (unsigned)p.ldc2;
 #pragma unroll
 	for (int tm = 0; tm < 4; ++tm)
@@ -205,15 +251,28 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		for (int i = 0; i < 4; ++i) {
 			const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
 			T* const crow = ctile + ((unsigned)lr * ldc32 + (unsigned)(wn * 64 + r16));
-			T* const c2row = c2tile + ((unsigned)lr * ldc2_32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
 			for (int tn = 0; tn < 4; ++tn) {
 				if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
-				const T v = acc[tm][tn][i];
-				crow[tn * 16] = v;
-				if (c2tile) c2row[tn * 16] = v;
+				if (SUB && DMA) acc[tm][tn][i] = -acc[tm][tn][i];
+				crow[tn * 16] = acc[tm][tn][i];
 			}
 		}
+	if (p.C2) {         // second copy (panel workspace of potrf): one uniform branch around all its stores
+		T* const c2tile = p.C2 + (int64_t)row0 * p.ldc2 + col0;
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+				T* const c2row = c2tile + ((unsigned)lr * ldc2_32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) {
+					if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
+					c2row[tn * 16] = acc[tm][tn][i];
+				}
+			}
+	}
 }
 
 template <typename T>
@@ -233,6 +292,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.tiles_m = (int)((m + BM - 1) / BM);
 	p.tiles_n = (int)((n + BN - 1) / BN);
 	p.mode = mode;
+	p.exp = g_gemm_exp;
 	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
 	p.bc_nbt = 0; p.bc_pr = p.bc_pc = 1; p.bc_myr = p.bc_myc = p.bc_i0 = p.bc_j0 = 0;
 	if (bc) {
