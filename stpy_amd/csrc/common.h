@@ -48,9 +48,11 @@ template <> struct Mfma<float> {
 
 // ---- internal launchers (all enqueue on `st`, return 0 or a negative error code) ----
 struct BlockCyclic { int nb_dist, pr, pc, myr, myc, i0, j0; };
+template <typename T> struct RffEpilogue { int half; T scale; const T* bias; };
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
-            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr);
+            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
+            const RffEpilogue<T>* rff = nullptr);
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st);
 template <typename T>

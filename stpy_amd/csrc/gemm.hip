@@ -41,7 +41,10 @@ struct GemmArgs {
 	int st_m, st_n;          // super-tile shape in tiles (st_m * st_n == 64)
 	int nst_m, nst_n;        // super-tile grid
 	int nsuper;              // number of super-tiles enumerated
-	int mode;                // 0: C = AB^T   1: C -= AB^T
+	int mode;                // 0: C = AB^T   1: C -= AB^T   2: C = rff(AB^T) (fused random-Fourier-feature epilogue)
+	int epi_half;            // mode 2: columns < epi_half take cos, the rest sin (all cos when epi_bias != null)
+	T epi_scale;             // mode 2: output scale sqrt(2/m) sqrt(kappa)
+	const T* epi_bias;       // mode 2: optional phase per column
 	int tri;                 // 1: lower-triangular tile set (square C), super-tiles enumerated over the lower triangle
 	int stagger;             // >0: first-round workgroups in the odd wave slot of their SIMD start this many cycles late
 	// block-cyclic "staircase" (multi-GPU local trailing update): C is a window of a rank's local
@@ -51,6 +54,22 @@ struct GemmArgs {
 	int bc_nbt, bc_pr, bc_pc, bc_myr, bc_myc, bc_i0, bc_j0;
 	int exp;                 // timing experiments (0 in production)
 };
+
+// Random-Fourier-feature epilogue: scale * cos(q + b) or scale * sin(q).  fp64: libm-accurate.
+// fp32: the phase is reduced to revolutions in fp32 (q/2pi minus its nearest integer, exact for
+// |q/2pi| < 2^22) and fed to the hardware v_sin_f32 / v_cos_f32 (input in revolutions); absolute
+// error ~1e-6 on a value that is then scaled by sqrt(2/m).
+template <typename T> __device__ __forceinline__ T rff_value(T q, bool use_cos, T scale);
+template <> __device__ __forceinline__ double rff_value<double>(double q, bool use_cos, double scale)
+{
+	return scale * (use_cos ? cos(q) : sin(q));
+}
+template <> __device__ __forceinline__ float rff_value<float>(float q, bool use_cos, float scale)
+{
+	float t = q * 0.15915494309189535f;
+	t -= rintf(t);
+	return scale * (use_cos ? __builtin_amdgcn_cosf(t) : __builtin_amdgcn_sinf(t));
+}
 
 template <typename T, bool GUARD, bool SUB>
 __global__ __launch_bounds__(NTHREADS, 2)
@@ -255,6 +274,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			for (int tn = 0; tn < 4; ++tn) {
 				if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
 				if (SUB && DMA) acc[tm][tn][i] = -acc[tm][tn][i];
+				if (!SUB && p.mode == 2) {
+					const int col = col0 + wn * 64 + r16 + tn * 16;
+					const T q = p.epi_bias ? acc[tm][tn][i] + p.epi_bias[col] : acc[tm][tn][i];
+					acc[tm][tn][i] = rff_value<T>(q, p.epi_bias != nullptr || col < p.epi_half, p.epi_scale);
+				}
 				crow[tn * 16] = acc[tm][tn][i];
 			}
 		}
@@ -277,7 +301,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
-            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc)
+            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc, const RffEpilogue<T>* rff)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (k <= 0) {
@@ -292,6 +316,11 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.tiles_m = (int)((m + BM - 1) / BM);
 	p.tiles_n = (int)((n + BN - 1) / BN);
 	p.mode = mode;
+	p.epi_half = 0; p.epi_scale = T(1); p.epi_bias = nullptr;
+	if (mode == 2) {
+		if (!rff) { set_error("gemm_nt: mode 2 needs the RFF epilogue parameters"); return -12; }
+		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias;
+	}
 	p.exp = g_gemm_exp;
 	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
 	p.bc_nbt = 0; p.bc_pr = p.bc_pc = 1; p.bc_myr = p.bc_myc = p.bc_i0 = p.bc_j0 = 0;
@@ -332,7 +361,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	return check_launch("gemm_nt");
 }
 
-template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*);
-template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*);
+template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*);
+template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*);
 
 }  // namespace stpy

@@ -77,9 +77,9 @@ def exp_gemm():
 	C = torch.randn(n, n, dtype=torch.float64, device=dev)
 	f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, 1, 1, L.stream_ptr()), "gemm")
 	names = {0: "baseline", 1: "no global loads after tile 0", 3: "no loads, no LDS stores", 7: "no loads/stores/barrier", 15: "same + no buffer flip",
-			 2: "loads kept, no LDS stores", 6: "loads kept, no stores, no barrier", 4: "no barrier only (racy)"}
+			 16: "no L2 warm-up touch", 2: "loads kept, no LDS stores", 6: "loads kept, no stores, no barrier", 4: "no barrier only (racy)"}
 	for rnd in range(2):
-		for e in (0, 1, 3, 7, 15, 2, 6, 4):
+		for e in (0, 16, 1, 4):
 			lib.stpy_tune(1, e)
 			t = timeit(f, reps=2, warm=1)[0]
 			print("exp=%2d %-36s %.3f ms  %.1f TF" % (e, names[e], t * 1e3, float(n) * n * k / t / 1e12), flush=True)
