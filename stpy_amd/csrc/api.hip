@@ -195,6 +195,7 @@ void stpy_tune(int key, int value)
 {
 	if (key == 0) g_gemm_stagger = value;
 	if (key == 1) g_gemm_exp = value;
+	if (key == 2) g_potf2_scalar = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */

@@ -12,6 +12,7 @@ constexpr int IB = 128;          // inner (diagonal) block of the factorisation 
 
 extern int g_gemm_stagger;
 extern int g_gemm_exp;
+extern int g_potf2_scalar;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

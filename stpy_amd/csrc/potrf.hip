@@ -15,6 +15,7 @@
 
 namespace stpy {
 
+int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B runs)
 constexpr int PT_THREADS = 512;
 constexpr int SLD = 132;     // LDS row stride in elements: 132 = 4 (mod 32) keeps the (row, k mod 4) lane map conflict-free
 
@@ -134,18 +135,205 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA-blocked version of the same job (the default): the 128x128 block is processed in 16-wide
+// sub-blocks so that only the 16x16 diagonal sub-blocks see a serial pivot chain (one wave, rows in
+// registers, v_readlane broadcasts -- no LDS, no barriers inside it); the 16-wide panel below it,
+// the trailing update and the whole triangular inverse are 16x16x16 products on the MFMA, fed from
+// LDS.  3 workgroup barriers per 16 columns instead of 2 per column.
+//   S   [128][SLD]   the block; lower part L as it is produced; strictly-upper BLOCKS (j,i), i>j,
+//                    later receive W_ij^T -- exactly the "row x K" image the MFMA B operand reads
+//   WD  [8][16][17]  inverse of every 16x16 diagonal sub-block of L
+// W = inverse(L): W_ii = WD_i;  W_ij = -WD_i * sum_{k=j}^{i-1} L_ik W_kj  for i > j; wave j owns
+// block column j, no workgroup barrier is needed while the eight columns advance.
+// ------------------------------------------------------------------------------------------
+constexpr int SB = 16, NSB = IB / SB, WLD = 17;
+constexpr int SLM = 130;    // LDS row stride of the MFMA kernel: 130 = 2 (mod 32) -> the (row, k) operand reads of a 32-lane half hit 32 distinct 8-byte banks
+
+// broadcast of one lane's value to the whole wave through SGPRs (v_readlane), lane index uniform
+__device__ __forceinline__ double bcast(double v, int src)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bcast(float v, int src)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+template <typename T>
+__global__ __launch_bounds__(PT_THREADS)
+void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__ W,
+                             T* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
+{
+	typedef Mfma<T> MM;
+	typedef typename MM::v4 v4;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	T* S = reinterpret_cast<T*>(smem_raw);          // [128][SLM]
+	T* WD = S + IB * SLM;                           // [8][16][WLD]
+	T* SC = WD + NSB * SB * WLD;                    // [8 waves][16][WLD] scratch (fp32 operand re-layout)
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int r16 = lane & 15, g = lane >> 4;
+
+	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
+		const int i = idx >> 7, j = idx & 127;
+		T v = T(0);
+		if (i < nbk && j <= i) v = A[(int64_t)i * lda + j];
+		else if (i >= nbk && i == j) v = T(1);
+		S[i * SLM + j] = v;
+	}
+	__syncthreads();
+
+	for (int kb = 0; kb < NSB; ++kb) {
+		const int o = kb * SB;
+		if (wave == 0) {
+			// ---- 16x16 diagonal sub-block: lane i (< 16) holds row i in registers
+			T r[SB];
+#pragma unroll
+			for (int k = 0; k < SB; ++k) r[k] = (lane < SB && k <= lane) ? S[(o + lane) * SLM + o + k] : T(0);
+			T myrinv = T(1);
+#pragma unroll
+			for (int j = 0; j < SB; ++j) {
+				T d = bcast(r[j], j);
+				if (!(d > T(0)) || !(d < T(1e300))) {
+					if (lane == 0) atomicCAS(info, 0, block_row0 + o + j + 1);
+					d = T(1);
+				}
+				const T l = sqrt(d), rl = T(1) / l;
+				r[j] = (lane == j) ? l : r[j] * rl;
+				if (lane == j) myrinv = rl;
+#pragma unroll
+				for (int k = j + 1; k < SB; ++k) {
+					const T lkj = bcast(r[j], k);
+					const T upd = r[k] - r[j] * lkj;
+					r[k] = (lane >= k) ? upd : r[k];
+				}
+				__builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of later pivots from being hoisted (register pressure)
+			}
+			// ---- inverse of the 16x16 factor: lane c holds column c of W
+			T wc[SB];
+#pragma unroll
+			for (int i = 0; i < SB; ++i) {
+				T acc = (lane == i) ? T(1) : T(0);
+#pragma unroll
+				for (int k = 0; k < i; ++k) acc -= bcast(r[k], i) * wc[k];
+				wc[i] = acc * bcast(myrinv, i);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			if (lane < SB) {
+#pragma unroll
+				for (int k = 0; k < SB; ++k) {
+					if (k <= lane) S[(o + lane) * SLM + o + k] = r[k];
+					WD[(kb * SB + k) * WLD + lane] = wc[k];            // W[k][c = lane]
+				}
+			}
+		}
+		__syncthreads();
+		// ---- panel below: X_bi = A_bi * WD^T   (one sub-block per wave)
+		for (int bi = kb + 1 + wave; bi < NSB; bi += 8) {
+			v4 acc = v4{0, 0, 0, 0};
+#pragma unroll
+			for (int s4 = 0; s4 < 4; ++s4)
+				acc = MM::mma(S[(bi * SB + r16) * SLM + o + 4 * s4 + g], WD[(kb * SB + r16) * WLD + 4 * s4 + g], acc);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) S[(bi * SB + MM::crow(lane, q)) * SLM + o + r16] = acc[q];
+		}
+		__syncthreads();
+		// ---- trailing sub-blocks (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T
+		{
+			const int nrem = NSB - 1 - kb, npair = nrem * (nrem + 1) / 2;
+			for (int pidx = wave; pidx < npair; pidx += 8) {
+				int a = 0, rem = pidx;
+				while (rem > a) { rem -= a + 1; ++a; }
+				const int bi = kb + 1 + a, bj = kb + 1 + rem;
+				v4 acc;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) acc[q] = S[(bi * SB + MM::crow(lane, q)) * SLM + bj * SB + r16];
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4)
+					acc = MM::mma(-S[(bi * SB + r16) * SLM + o + 4 * s4 + g], S[(bj * SB + r16) * SLM + o + 4 * s4 + g], acc);
+#pragma unroll
+				for (int q = 0; q < 4; ++q) S[(bi * SB + MM::crow(lane, q)) * SLM + bj * SB + r16] = acc[q];
+			}
+		}
+		__syncthreads();
+	}
+
+	// ---- write L back (and the panel copy with explicit zeros above the diagonal)
+	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
+		const int i = idx >> 7, j = idx & 127;
+		if (i < nbk && j < nbk) {
+			const T v = (j <= i) ? S[i * SLM + j] : T(0);
+			if (j <= i) A[(int64_t)i * lda + j] = v;
+			if (P2) P2[(int64_t)i * ldp2 + j] = v;
+		}
+	}
+	__syncthreads();
+
+	// ---- triangular inverse, block column `wave`
+	if (wave < NSB - 1) {
+		const int j = wave;
+		T* sc = SC + wave * SB * WLD;
+		for (int i = j + 1; i < NSB; ++i) {
+			v4 t = v4{0, 0, 0, 0};
+			for (int k = j; k < i; ++k) {
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4) {
+					const T a = S[(i * SB + r16) * SLM + k * SB + 4 * s4 + g];                       // L_ik[r16][kk]
+					const T b = (k == j) ? WD[(j * SB + 4 * s4 + g) * WLD + r16]                      // W_jj[kk][c]
+					                     : S[(j * SB + r16) * SLM + k * SB + 4 * s4 + g];             // (W_kj^T)[c][kk]
+					t = MM::mma(a, b, t);
+				}
+			}
+			v4 w = v4{0, 0, 0, 0};
+			if (sizeof(T) == 8) {
+				// fp64 C/D map: reg s of lane l is T[(l>>4) + 4s][l&15] -- already the B operand of k-step s
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], t[s4], w);
+			} else {
+#pragma unroll
+				for (int q = 0; q < 4; ++q) sc[MM::crow(lane, q) * WLD + r16] = t[q];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], sc[(4 * s4 + g) * WLD + r16], w);
+			}
+			// store W_ij transposed into block (j, i) of S: (W_ij^T)[c][r] = W_ij[r][c]
+#pragma unroll
+			for (int q = 0; q < 4; ++q) S[(j * SB + r16) * SLM + i * SB + MM::crow(lane, q)] = w[q];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	__syncthreads();
+	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
+		const int i = idx >> 7, c = idx & 127;
+		const int bi = i >> 4, bj = c >> 4;
+		T v = T(0);
+		if (bj == bi) v = WD[(bi * SB + (i & 15)) * WLD + (c & 15)];
+		else if (bj < bi) v = S[c * SLM + i];
+		W[idx] = v;
+	}
+}
+
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st)
 {
-	const size_t lds = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
+	const size_t lds_old = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
+	const size_t lds_new = (size_t)(IB * SLM + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
 	static bool attr_set[2] = {false, false};
 	const int which = sizeof(T) == 8 ? 0 : 1;
 	if (!attr_set[which]) {
-		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (e != hipSuccess) { set_error("potf2: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e)); return -1000 - (int)e; }
+		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
+		if (e != hipSuccess) { set_error("potf2: hipFuncSetAttribute(%zu B LDS) failed: %s", lds_new, hipGetErrorString(e)); return -1000 - (int)e; }
 		attr_set[which] = true;
 	}
-	hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(PT_THREADS), lds, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	if (g_potf2_scalar)
+		hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(PT_THREADS), lds_old, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	else
+		hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	return check_launch("potf2_trtri");
 }
 

@@ -86,8 +86,32 @@ def exp_gemm():
 	lib.stpy_tune(1, 0)
 
 
+def ab_fit(key, values, sizes=((16384, 8), (65536, 16))):
+	"""interleaved A/B of a tune knob on the whole fit+mean_std step (one process)"""
+	sys.path.insert(0, ".")
+	from bench import synth
+	from stpy_amd import GaussianProcess
+	import math
+	for n, d in sizes:
+		x, y, xt = synth(n, d, 4096, dev)
+		gp = GaussianProcess(gamma=math.sqrt(d), s=0.1, kernel_name="squared_exponential", d=d)
+		def step():
+			gp.fit_gp(x, y)
+			return gp.mean_std(xt)
+		res = {v: [] for v in values}
+		for rnd in range(3):
+			for v in values:
+				lib.stpy_tune(key, v)
+				res[v].append(timeit(step, reps=1, warm=1 if rnd == 0 else 0)[0])
+		print("n=%d tune(%d): " % (n, key) + "  ".join("%d -> %.4f s" % (v, min(res[v])) for v in values), flush=True)
+		del gp, x, y, xt
+		torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "abfit":
+		ab_fit(int(sys.argv[2]), [int(v) for v in sys.argv[3].split(",")])
 	if which == "exp":
 		exp_gemm()
 	if which == "ab":
