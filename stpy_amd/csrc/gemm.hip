@@ -60,9 +60,9 @@ struct GemmArgs {
 // |q/2pi| < 2^22) and fed to the hardware v_sin_f32 / v_cos_f32 (input in revolutions); absolute
 // error ~1e-6 on a value that is then scaled by sqrt(2/m).
 template <typename T> __device__ __forceinline__ T rff_value(T q, bool use_cos, T scale);
-template <> __device__ __forceinline__ double rff_value<double>(double q, bool use_cos, double scale)
+template <> __device__ __forceinline__ double rff_value<double>(double q, bool, double)
 {
-	return scale * (use_cos ? cos(q) : sin(q));
+	return q;       // never used: fp64 takes the unfused path (see the epilogue note)
 }
 template <> __device__ __forceinline__ float rff_value<float>(float q, bool use_cos, float scale)
 {
@@ -176,18 +176,27 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			dma_b[i] = p.B + (int64_t)(col0 + r) * p.ldb + c * 2;
 		}
 	}
+	// One LDS-DMA wave-instruction, issued through inline asm ON PURPOSE: with the builtin, hipcc
+	// models the DMA as an LDS store and (in some instantiations of this kernel) orders the next
+	// ds_read behind it with s_waitcnt vmcnt(0) -- the prefetch is then drained before the MFMAs
+	// start and the whole pipeline serialises (measured 5x slower).  The asm form is invisible to
+	// that bookkeeping; the matching wait is the explicit vmcnt(0) in front of the barrier below.
+	// M0 (LDS destination base) is saved and restored inside the statement (guide section 5.7).
+	auto dma_one = [&](const T* gsrc, T* ldst) {
+		const unsigned laddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)ldst;
+		unsigned keep;
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep) : "v"(gsrc), "s"(laddr) : "memory");
+	};
 	auto dma_issue = [&](int buf, int k0) {
 		const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			T* la = As + (buf * BM + wv * 32 + i * 8) * BK;
-			T* lb = Bs + (buf * BN + wv * 32 + i * 8) * BK;
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_a[i] + k0),
-			                                 (__attribute__((address_space(3))) void*)la, 16, 0, 0);
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_b[i] + k0),
-			                                 (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
+			dma_one(dma_a[i] + k0, As + (buf * BM + wv * 32 + i * 8) * BK);
+			dma_one(dma_b[i] + k0, Bs + (buf * BN + wv * 32 + i * 8) * BK);
 		}
 	};
+	auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
 	// ---- desynchronise the two workgroups that share a CU (see the note at the launch site)
 	if (p.stagger > 0 && b < 512) {
@@ -228,7 +237,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		}
 
 	if (!DMA) lstore(0);
-	__syncthreads();            // (with LDS-DMA in flight hipcc's barrier drains vmcnt(0) first: the tile has landed)
+	else dma_wait();
+	__syncthreads();
 	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);     // read-side swizzle of this lane's rows (row & 15 == r16)
 	int buf = 0;
 	for (int kt = 0; kt < KT; ++kt) {
@@ -258,8 +268,32 @@ void gemm_nt_kernel(GemmArgs<T> p)
 						acc[tm][tn] = MM::mma(fa[tm][s], fb[tn][s], acc[tm][tn]);
 		}
 		if (!DMA && kt + 1 < KT && !(p.exp & 2)) lstore(buf ^ 1);
+		if (DMA) dma_wait();       // this wave's pieces of the next tile have landed; the barrier publishes them
 		if (!(p.exp & 4)) __syncthreads();
 		if (!(p.exp & 8)) buf ^= 1;
+	}
+
+	// ---- fused random-Fourier-feature epilogue: ONE uniform branch around the whole transform (a
+	// ---- per-element runtime test would make hipcc branch and wait around every element)
+	// fp32 only: the fp64 libm sin/cos bodies are so large that hipcc stops unrolling the loops below,
+	// indexes `acc` at run time and moves ALL accumulators to scratch -- for every use of the
+	// kernel, 5x slower (guide rule 20).  fp64 embeds take the unfused route in rff.hip instead.
+	if (!SUB && sizeof(T) == 4 && p.mode == 2) {
+		T bias[4];
+		bool use_cos[4];
+#pragma unroll
+		for (int tn = 0; tn < 4; ++tn) {
+			const int col = col0 + wn * 64 + r16 + tn * 16;
+			bias[tn] = p.epi_bias ? p.epi_bias[GUARD ? min(col, p.n - 1) : col] : T(0);
+			use_cos[tn] = p.epi_bias != nullptr || col < p.epi_half;
+		}
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + bias[tn], use_cos[tn], p.epi_scale);
 	}
 
 	// ---- epilogue: reg i of tile (tm,tn) is C[row0 + wm*64 + tm*16 + crow(lane,i)][col0 + wn*64 + tn*16 + r16]
@@ -274,11 +308,6 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			for (int tn = 0; tn < 4; ++tn) {
 				if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
 				if (SUB && DMA) acc[tm][tn][i] = -acc[tm][tn][i];
-				if (!SUB && p.mode == 2) {
-					const int col = col0 + wn * 64 + r16 + tn * 16;
-					const T q = p.epi_bias ? acc[tm][tn][i] + p.epi_bias[col] : acc[tm][tn][i];
-					acc[tm][tn][i] = rff_value<T>(q, p.epi_bias != nullptr || col < p.epi_half, p.epi_scale);
-				}
 				crow[tn * 16] = acc[tm][tn][i];
 			}
 		}
@@ -318,7 +347,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.mode = mode;
 	p.epi_half = 0; p.epi_scale = T(1); p.epi_bias = nullptr;
 	if (mode == 2) {
-		if (!rff) { set_error("gemm_nt: mode 2 needs the RFF epilogue parameters"); return -12; }
+		if (!rff || sizeof(T) != 4) { set_error("gemm_nt: mode 2 (fused RFF epilogue) is fp32 only and needs its parameters"); return -12; }
 		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias;
 	}
 	p.exp = g_gemm_exp;

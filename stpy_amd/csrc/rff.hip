@@ -1,11 +1,14 @@
 // rff.hip -- random Fourier feature embed  Z[i][j] = c * {cos | sin}(<W_j, x_i> (+ b_j)).
 //
-// The phase matrix X W^T is an NT contraction with K = d, so it runs on the MFMA GEMM of gemm.hip
-// (fp32: v_mfma_f32_16x16x4_f32, fp64: v_mfma_f64_16x16x4_f64) with the trig + scale fused into the
-// store epilogue: the n x m phase matrix never exists in memory (the reference materialises it four
-// times, embedding.py:234-241) and the vector ALU is left for the sin/cos.  At C5 (d = 64, fp32) the
-// contraction (1.1e12 flop) and the 34 GB of output are about equally expensive, so neither a
-// VALU dot product nor an unfused GEMM + elementwise pass can reach the HBM roofline.
+// The phase matrix X W^T is an NT contraction with K = d, so it runs on the MFMA GEMM of gemm.hip.
+//   fp32 (the performance configuration, BASELINE config 5): trig + scale are fused into the GEMM's
+//        store epilogue (hardware v_sin_f32 / v_cos_f32 on the phase reduced to revolutions); the
+//        n x m phase matrix never exists in memory (the reference materialises it four times,
+//        embedding.py:234-241).  At d = 64 the contraction (1.1e12 flop) and the 34 GB of output
+//        cost about the same, so neither a VALU dot product nor an unfused pass reaches the roofline.
+//   fp64 (the reference's dtype, used for parity): GEMM into `out`, then one in-place elementwise
+//        pass with libm-accurate sin/cos.  (Fusing the fp64 libm bodies into the GEMM epilogue makes
+//        hipcc spill every accumulator to scratch.)
 //
 // Column layout quirk kept from the reference (embedding.py:236-239): without a bias the cos
 // half uses frequency rows 0..m/2-1 and the sin half uses the *other* rows m/2..m-1.
@@ -13,17 +16,47 @@
 
 namespace stpy {
 
+__global__ __launch_bounds__(256)
+void rff_trig_f64_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias, double scale)
+{
+	const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	const int64_t total = n * (int64_t)(m / 2);
+	if (idx >= total) return;
+	const int64_t i = idx / (m / 2);
+	const int j = (int)(idx - i * (m / 2)) * 2;           // two adjacent features per thread: 16-byte accesses
+	double* o = out + i * ldo + j;
+	double q0 = o[0], q1 = o[1];
+	if (bias) { q0 += bias[j]; q1 += bias[j + 1]; }
+	o[0] = scale * ((bias || j < half) ? cos(q0) : sin(q0));
+	o[1] = scale * ((bias || j + 1 < half) ? cos(q1) : sin(q1));
+}
+
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
-              const T* bias, double scale, T* out, int64_t ldo, hipStream_t st)
+              const T* bias, double scale, T* out, int64_t ldo, hipStream_t st);
+
+template <>
+int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float* W, int64_t ldw, int64_t m,
+                     const float* bias, double scale, float* out, int64_t ldo, hipStream_t st)
 {
 	if (n <= 0 || m <= 0) return 0;
 	if (m % 2 != 0) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
-	RffEpilogue<T> epi{(int)(m / 2), (T)scale, bias};
-	return gemm_nt<T>(n, m, d, x, ldx, W, ldw, out, ldo, (T*)nullptr, 0, 2, 0, st, nullptr, &epi);
+	RffEpilogue<float> epi{(int)(m / 2), (float)scale, bias};
+	return gemm_nt<float>(n, m, d, x, ldx, W, ldw, out, ldo, (float*)nullptr, 0, 2, 0, st, nullptr, &epi);
 }
 
-template int rff_embed<double>(const double*, int64_t, int64_t, int, const double*, int64_t, int64_t, const double*, double, double*, int64_t, hipStream_t);
-template int rff_embed<float>(const float*, int64_t, int64_t, int, const float*, int64_t, int64_t, const float*, double, float*, int64_t, hipStream_t);
+template <>
+int rff_embed<double>(const double* x, int64_t n, int64_t ldx, int d, const double* W, int64_t ldw, int64_t m,
+                      const double* bias, double scale, double* out, int64_t ldo, hipStream_t st)
+{
+	if (n <= 0 || m <= 0) return 0;
+	if (m % 2 != 0) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
+	if (m > INT32_MAX) { set_error("rff_embed: m exceeds int32"); return -7; }
+	int rc = gemm_nt<double>(n, m, d, x, ldx, W, ldw, out, ldo, (double*)nullptr, 0, 0, 0, st);
+	if (rc) return rc;
+	const int64_t total = n * (m / 2);
+	hipLaunchKernelGGL(rff_trig_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, ldo, n, (int)m, (int)(m / 2), bias, scale);
+	return check_launch("rff_trig_f64");
+}
 
 }  // namespace stpy

@@ -1,0 +1,69 @@
+"""
+Build-level guards that need no GPU: the C-ABI library exports every symbol of include/stpy_hip.h,
+and the MFMA GEMM instantiations keep their accumulators in registers (no scratch, no VGPR
+spills) -- a rolled loop over the accumulator array once sent them all to scratch and made one
+instantiation 5x slower without failing any numerical test.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "stpy_amd", "csrc")
+
+
+def test_header_symbols_exported():
+	from stpy_amd import _lib
+	lib = _lib.load()
+	header = open(os.path.join(ROOT, "include", "stpy_hip.h")).read()
+	declared = set(re.findall(r"\b(stpy_[a-z0-9_]+)\s*\(", header))
+	assert declared, "no declarations parsed"
+	for name in declared:
+		assert hasattr(lib, name), "libstpy_hip.so lacks %s" % name
+	assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+	assert lib.stpy_version().startswith(b"stpy_hip")
+
+
+def test_no_cpu_fallback_without_gpu():
+	import torch
+	if torch.cuda.is_available():
+		pytest.skip("GPU present")
+	import stpy_amd
+	from stpy_amd._lib import StpyHipError
+	with pytest.raises(StpyHipError):
+		stpy_amd.KernelFunction(d=2).kernel(torch.zeros(3, 2).double(), torch.zeros(3, 2).double())
+	with pytest.raises(StpyHipError):
+		stpy_amd.GaussianProcess(d=2).fit_gp(torch.zeros(3, 2).double(), torch.zeros(3, 1).double())
+
+
+def test_product_does_not_import_oracle():
+	for dirpath, _, files in os.walk(os.path.join(ROOT, "stpy_amd")):
+		for f in files:
+			if f.endswith(".py"):
+				src = open(os.path.join(dirpath, f)).read()
+				assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), "%s imports the oracle" % f
+				assert "/root/reference" not in src
+
+
+@pytest.mark.parametrize("src", ["gemm.hip", "potrf.hip"])
+def test_mfma_kernels_stay_in_registers(src, tmp_path):
+	out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", os.path.join(CSRC, src),
+						  "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True).stderr
+	blocks = re.split(r"remark: Function Name: ", out)[1:]
+	seen = 0
+	for b in blocks:
+		name = b.split()[0]
+		if "gemm_nt_kernel" not in name and "potf2_trtri_mfma_kernel" not in name:
+			continue
+		seen += 1
+		scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+		vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+		vgprs = int(re.search(r"\bVGPRs: (\d+)", b).group(1))
+		if "gemm_nt_kernel" in name:
+			assert vspill <= 2 and scratch <= 16, (name, scratch, vspill)       # (2 VGPRs outside the K loop in one instantiation)
+			assert vgprs <= 256
+		else:
+			assert vspill == 0 and scratch == 0, (name, scratch, vspill)
+	assert seen >= 2

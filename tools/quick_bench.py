@@ -108,8 +108,21 @@ def ab_fit(key, values, sizes=((16384, 8), (65536, 16))):
 		torch.cuda.empty_cache()
 
 
+def small_k():
+	n = 32768
+	C = torch.randn(n, n, dtype=torch.float64, device=dev)
+	for k in (16, 32, 64, 128, 256, 512):
+		P = torch.randn(n, k, dtype=torch.float64, device=dev)
+		for mode in (1, 0):
+			f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, mode, 1, L.stream_ptr()), "gemm")
+			t = timeit(f, reps=3, warm=1)[0]
+			print("n=%d k=%4d mode=%d: %.3f ms  (%.2f us per round of 512 tiles)  C-bytes/time = %.2f TB/s" % (n, k, mode, t * 1e3, t * 1e6 / (32896 / 512.0), (2 if mode else 1) * n * n * 4 / t / 1e12), flush=True)
+
+
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "smallk":
+		small_k()
 	if which == "abfit":
 		ab_fit(int(sys.argv[2]), [int(v) for v in sys.argv[3].split(",")])
 	if which == "exp":
