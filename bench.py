@@ -143,6 +143,19 @@ def main():
 	g_cnt = pr["syrk"][2] + pr["panel_gemm"][2] + pr["trsm_gemm"][2]
 	achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
 
+	# HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
+	# value comes from the committed separate-pass rocprofv3 --pmc runs of this same command
+	# (profiles/*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch.
+	traffic = None
+	try:
+		import glob
+		cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+		if cands and n == 65536 and d == 16 and m == 4096 and world == 1:
+			with open(cands[-1]) as fh:
+				traffic = round(json.load(fh)["per_launch_hbm_bytes"])
+	except Exception:
+		traffic = None
+
 	if rank == 0:
 		F = flops_fit_predict(n, m)
 		out = {
@@ -156,7 +169,8 @@ def main():
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),
 			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_kernel<double,false>", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
-						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
+						 "traffic_note": "HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes of this command (profiles/), 2*FETCH_SIZE + WRITE_SIZE",
 						 "launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4),
 						 "algorithmic_gflop_per_launch": round(g_fl / max(g_cnt, 1) / 1e9, 3)},
 			"breakdown_ms_per_step": {k: round(v[0] / args.steps, 2) for k, v in pr.items()},
