@@ -141,7 +141,10 @@ def main():
 	g_ms = pr["syrk"][0] + pr["panel_gemm"][0] + pr["trsm_gemm"][0]
 	g_fl = pr["syrk"][1] + pr["panel_gemm"][1] + pr["trsm_gemm"][1]
 	g_cnt = pr["syrk"][2] + pr["panel_gemm"][2] + pr["trsm_gemm"][2]
-	achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+	# launches on the look-ahead stream overlap the trailing update: time them as the union of intervals
+	ub, uf, uc = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+	_lib.check(lib.stpy_profile_read_union(0b0111, ctypes.byref(ub), ctypes.byref(uf), ctypes.byref(uc)), "stpy_profile_read_union")
+	achieved = uf.value / (ub.value * 1e-3) / 1e12 if ub.value > 0 else 0.0
 
 	# HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
 	# value comes from the committed separate-pass rocprofv3 --pmc runs of this same command
@@ -171,7 +174,7 @@ def main():
 			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_kernel<double,false>", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
 						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
 						 "traffic_note": "HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes of this command (profiles/), 2*FETCH_SIZE + WRITE_SIZE",
-						 "launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4),
+						 "launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4), "busy_ms_per_step": round(ub.value / args.steps, 2),
 						 "algorithmic_gflop_per_launch": round(g_fl / max(g_cnt, 1) / 1e9, 3)},
 			"breakdown_ms_per_step": {k: round(v[0] / args.steps, 2) for k, v in pr.items()},
 			"result_check": {"mu_norm": float(torch.norm(mu)), "std_mean": float(std.mean()), "nan": bool(torch.isnan(std).any())},

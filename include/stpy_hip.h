@@ -147,6 +147,8 @@ void stpy_profile_enable(int enable);
 /* tuning knob for A/B benchmarks: key 0 = first-round workgroup stagger of the GEMM (default 1) */
 void stpy_tune(int key, int value);
 int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* launches);
+/* union of the launch intervals of all tags in tagmask (bit t = tag t): overlapping launches counted once */
+int stpy_profile_read_union(int tagmask, double* busy_ms, double* total_flops, int64_t* launches);
 
 #ifdef __cplusplus
 }

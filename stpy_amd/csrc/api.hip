@@ -1,6 +1,8 @@
 // api.hip -- the extern "C" surface of libstpy_hip.so (see include/stpy_hip.h).
 #include <stdarg.h>
 #include <string.h>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -217,6 +219,40 @@ int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* l
 		ms += t; fl += g_prof[i].flops; ++cnt;
 	}
 	if (total_ms) *total_ms = ms;
+	if (total_flops) *total_flops = fl;
+	if (launches) *launches = cnt;
+	return 0;
+}
+
+/* Same records, but launches that overlap in time (look-ahead side stream) are not double counted:
+ * busy_ms = length of the union of the [start, end] intervals of all launches whose tag bit is set
+ * in tagmask (bit t = tag t). */
+int stpy_profile_read_union(int tagmask, double* busy_ms, double* total_flops, int64_t* launches)
+{
+	std::vector<std::pair<float, float>> iv;
+	double fl = 0;
+	int64_t cnt = 0;
+	hipEvent_t base = nullptr;
+	for (size_t i = 0; i < g_prof_used; ++i) {
+		if (!((tagmask >> g_prof[i].tag) & 1)) continue;
+		if (hipEventSynchronize(g_prof[i].e1) != hipSuccess) { set_error("stpy_profile_read_union: event sync failed"); return -1; }
+		if (!base) base = g_prof[i].e0;
+		float t0 = 0, t1 = 0;
+		if (hipEventElapsedTime(&t0, base, g_prof[i].e0) != hipSuccess || hipEventElapsedTime(&t1, base, g_prof[i].e1) != hipSuccess) {
+			set_error("stpy_profile_read_union: elapsed failed"); return -1;
+		}
+		iv.emplace_back(t0, t1);
+		fl += g_prof[i].flops; ++cnt;
+	}
+	std::sort(iv.begin(), iv.end());
+	double busy = 0;
+	float cs = 0, ce = -1;
+	for (auto& p : iv) {
+		if (ce < cs || p.first > ce) { if (ce >= cs) busy += ce - cs; cs = p.first; ce = p.second; }
+		else if (p.second > ce) ce = p.second;
+	}
+	if (ce >= cs && !iv.empty()) busy += ce - cs;
+	if (busy_ms) *busy_ms = busy;
 	if (total_flops) *total_flops = fl;
 	if (launches) *launches = cnt;
 	return 0;

@@ -139,16 +139,26 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 // MFMA-blocked version of the same job (the default): the 128x128 block is processed in 16-wide
 // sub-blocks so that only the 16x16 diagonal sub-blocks see a serial pivot chain (one wave, rows in
 // registers, v_readlane broadcasts -- no LDS, no barriers inside it); the 16-wide panel below it,
-// the trailing update and the whole triangular inverse are 16x16x16 products on the MFMA, fed from
-// LDS.  3 workgroup barriers per 16 columns instead of 2 per column.
-//   S   [128][SLD]   the block; lower part L as it is produced; strictly-upper BLOCKS (j,i), i>j,
-//                    later receive W_ij^T -- exactly the "row x K" image the MFMA B operand reads
+// the trailing update and the whole triangular inverse are 16x16x16 products on the MFMA.
+// 3 workgroup barriers per 16 columns instead of 2 per column.
+//
+// LDS budget matters more than anything else here: the kernel runs on the look-ahead stream while
+// the trailing-update GEMM keeps two 72 KiB workgroups on every CU.  A workgroup that needs more
+// LDS than ONE freed GEMM slot (+ the 16 KiB the GEMM pair leaves over) is never placed until the
+// GEMM grid drains -- measured: the 150 KiB version waited 2.8 ms on average for an 80 us job.
+// So the block is held as a PACKED lower triangle (row i at i(i+1)/2: 64.5 KiB fp64) plus the eight
+// 16x16 inverse diagonal blocks (17 KiB): 83 KiB.  The off-diagonal blocks of inverse(L) go straight
+// to the output array in global memory and are read back from there (L2-hot, written by the same
+// wave) when a later block of the same block column needs them.
+//   S   packed lower triangle of the block, L as it is produced
 //   WD  [8][16][17]  inverse of every 16x16 diagonal sub-block of L
 // W = inverse(L): W_ii = WD_i;  W_ij = -WD_i * sum_{k=j}^{i-1} L_ik W_kj  for i > j; wave j owns
 // block column j, no workgroup barrier is needed while the eight columns advance.
 // ------------------------------------------------------------------------------------------
 constexpr int SB = 16, NSB = IB / SB, WLD = 17;
-constexpr int SLM = 130;    // LDS row stride of the MFMA kernel: 130 = 2 (mod 32) -> the (row, k) operand reads of a 32-lane half hit 32 distinct 8-byte banks
+constexpr int TRI = IB * (IB + 1) / 2;
+
+__device__ __forceinline__ int tri(int i, int k) { return (i * (i + 1) >> 1) + k; }      // k <= i
 
 // broadcast of one lane's value to the whole wave through SGPRs (v_readlane), lane index uniform
 __device__ __forceinline__ double bcast(double v, int src)
@@ -164,24 +174,25 @@ __device__ __forceinline__ float bcast(float v, int src)
 
 template <typename T>
 __global__ __launch_bounds__(PT_THREADS)
-void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__ W,
+void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
                              T* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
 {
 	typedef Mfma<T> MM;
 	typedef typename MM::v4 v4;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	T* S = reinterpret_cast<T*>(smem_raw);          // [128][SLM]
-	T* WD = S + IB * SLM;                           // [8][16][WLD]
-	T* SC = WD + NSB * SB * WLD;                    // [8 waves][16][WLD] scratch (fp32 operand re-layout)
+	T* S = reinterpret_cast<T*>(smem_raw);          // [TRI] packed lower triangle
+	T* WD = S + TRI;                                // [8][16][WLD]
+	T* SC = WD + NSB * SB * WLD;                    // [8 waves][16][WLD] scratch (fp32 operand re-layout only)
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r16 = lane & 15, g = lane >> 4;
 
 	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
 		const int i = idx >> 7, j = idx & 127;
+		if (j > i) continue;
 		T v = T(0);
-		if (i < nbk && j <= i) v = A[(int64_t)i * lda + j];
-		else if (i >= nbk && i == j) v = T(1);
-		S[i * SLM + j] = v;
+		if (i < nbk) v = A[(int64_t)i * lda + j];
+		else if (i == j) v = T(1);
+		S[tri(i, j)] = v;
 	}
 	__syncthreads();
 
@@ -191,7 +202,7 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restr
 			// ---- 16x16 diagonal sub-block: lane i (< 16) holds row i in registers
 			T r[SB];
 #pragma unroll
-			for (int k = 0; k < SB; ++k) r[k] = (lane < SB && k <= lane) ? S[(o + lane) * SLM + o + k] : T(0);
+			for (int k = 0; k < SB; ++k) r[k] = (lane < SB && k <= lane) ? S[tri(o + lane, o + k)] : T(0);
 			T myrinv = T(1);
 #pragma unroll
 			for (int j = 0; j < SB; ++j) {
@@ -224,54 +235,66 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restr
 			if (lane < SB) {
 #pragma unroll
 				for (int k = 0; k < SB; ++k) {
-					if (k <= lane) S[(o + lane) * SLM + o + k] = r[k];
+					if (k <= lane) S[tri(o + lane, o + k)] = r[k];
 					WD[(kb * SB + k) * WLD + lane] = wc[k];            // W[k][c = lane]
 				}
 			}
 		}
 		__syncthreads();
-		// ---- panel below: X_bi = A_bi * WD^T   (one sub-block per wave)
+		// ---- panel below: X_bi = A_bi * WD^T   (one sub-block per wave; every element is strictly below the diagonal)
 		for (int bi = kb + 1 + wave; bi < NSB; bi += 8) {
 			v4 acc = v4{0, 0, 0, 0};
 #pragma unroll
 			for (int s4 = 0; s4 < 4; ++s4)
-				acc = MM::mma(S[(bi * SB + r16) * SLM + o + 4 * s4 + g], WD[(kb * SB + r16) * WLD + 4 * s4 + g], acc);
+				acc = MM::mma(S[tri(bi * SB + r16, o + 4 * s4 + g)], WD[(kb * SB + r16) * WLD + 4 * s4 + g], acc);
 #pragma unroll
-			for (int q = 0; q < 4; ++q) S[(bi * SB + MM::crow(lane, q)) * SLM + o + r16] = acc[q];
+			for (int q = 0; q < 4; ++q) S[tri(bi * SB + MM::crow(lane, q), o + r16)] = acc[q];
 		}
 		__syncthreads();
-		// ---- trailing sub-blocks (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T
+		// ---- trailing sub-blocks (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T  (diagonal sub-blocks: lower part only)
 		{
 			const int nrem = NSB - 1 - kb, npair = nrem * (nrem + 1) / 2;
 			for (int pidx = wave; pidx < npair; pidx += 8) {
 				int a = 0, rem = pidx;
 				while (rem > a) { rem -= a + 1; ++a; }
 				const int bi = kb + 1 + a, bj = kb + 1 + rem;
+				const bool diag = bi == bj;
 				v4 acc;
 #pragma unroll
-				for (int q = 0; q < 4; ++q) acc[q] = S[(bi * SB + MM::crow(lane, q)) * SLM + bj * SB + r16];
+				for (int q = 0; q < 4; ++q) {
+					const int rr = MM::crow(lane, q);
+					acc[q] = (!diag || r16 <= rr) ? S[tri(bi * SB + rr, bj * SB + r16)] : T(0);
+				}
 #pragma unroll
 				for (int s4 = 0; s4 < 4; ++s4)
-					acc = MM::mma(-S[(bi * SB + r16) * SLM + o + 4 * s4 + g], S[(bj * SB + r16) * SLM + o + 4 * s4 + g], acc);
+					acc = MM::mma(-S[tri(bi * SB + r16, o + 4 * s4 + g)], S[tri(bj * SB + r16, o + 4 * s4 + g)], acc);
 #pragma unroll
-				for (int q = 0; q < 4; ++q) S[(bi * SB + MM::crow(lane, q)) * SLM + bj * SB + r16] = acc[q];
+				for (int q = 0; q < 4; ++q) {
+					const int rr = MM::crow(lane, q);
+					if (!diag || r16 <= rr) S[tri(bi * SB + rr, bj * SB + r16)] = acc[q];
+				}
 			}
 		}
 		__syncthreads();
 	}
 
-	// ---- write L back (and the panel copy with explicit zeros above the diagonal)
+	// ---- write L back (and the panel copy with explicit zeros above the diagonal); inverse(L):
+	// ---- zeros above the diagonal and the diagonal sub-blocks now, off-diagonal blocks below
 	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
 		const int i = idx >> 7, j = idx & 127;
+		const T v = (j <= i) ? S[tri(i, j)] : T(0);
 		if (i < nbk && j < nbk) {
-			const T v = (j <= i) ? S[i * SLM + j] : T(0);
 			if (j <= i) A[(int64_t)i * lda + j] = v;
 			if (P2) P2[(int64_t)i * ldp2 + j] = v;
 		}
+		const int bi = i >> 4, bj = j >> 4;
+		if (bj > bi) W[idx] = T(0);
+		else if (bj == bi) W[idx] = WD[(bi * SB + (i & 15)) * WLD + (j & 15)];
 	}
-	__syncthreads();
+	// (no barrier needed: the inverse below reads S and WD only, and writes W blocks nobody else touches)
 
-	// ---- triangular inverse, block column `wave`
+	// ---- triangular inverse, block column `wave`; W_ij goes to global memory, later steps of the
+	// ---- same wave read W_kj back from there
 	if (wave < NSB - 1) {
 		const int j = wave;
 		T* sc = SC + wave * SB * WLD;
@@ -280,9 +303,9 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restr
 			for (int k = j; k < i; ++k) {
 #pragma unroll
 				for (int s4 = 0; s4 < 4; ++s4) {
-					const T a = S[(i * SB + r16) * SLM + k * SB + 4 * s4 + g];                       // L_ik[r16][kk]
+					const T a = S[tri(i * SB + r16, k * SB + 4 * s4 + g)];                            // L_ik[r16][kk]
 					const T b = (k == j) ? WD[(j * SB + 4 * s4 + g) * WLD + r16]                      // W_jj[kk][c]
-					                     : S[(j * SB + r16) * SLM + k * SB + 4 * s4 + g];             // (W_kj^T)[c][kk]
+					                     : W[(k * SB + 4 * s4 + g) * IB + j * SB + r16];              // W_kj[kk][c]
 					t = MM::mma(a, b, t);
 				}
 			}
@@ -299,21 +322,13 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restr
 #pragma unroll
 				for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], sc[(4 * s4 + g) * WLD + r16], w);
 			}
-			// store W_ij transposed into block (j, i) of S: (W_ij^T)[c][r] = W_ij[r][c]
 #pragma unroll
-			for (int q = 0; q < 4; ++q) S[(j * SB + r16) * SLM + i * SB + MM::crow(lane, q)] = w[q];
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
+			for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
+			// the next step of this wave re-reads these values: stores drained, then ordered before the loads
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		}
-	}
-	__syncthreads();
-	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
-		const int i = idx >> 7, c = idx & 127;
-		const int bi = i >> 4, bj = c >> 4;
-		T v = T(0);
-		if (bj == bi) v = WD[(bi * SB + (i & 15)) * WLD + (c & 15)];
-		else if (bj < bi) v = S[c * SLM + i];
-		W[idx] = v;
 	}
 }
 
@@ -321,7 +336,7 @@ template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st)
 {
 	const size_t lds_old = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
-	const size_t lds_new = (size_t)(IB * SLM + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
+	const size_t lds_new = (size_t)(TRI + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
 	static bool attr_set[2] = {false, false};
 	const int which = sizeof(T) == 8 ? 0 : 1;
 	if (!attr_set[which]) {
