@@ -167,7 +167,7 @@ def main():
 			"ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": False,
 			"scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
 			"config": {"workload": "GaussianProcess.fit_gp + mean_std, SE kernel gamma=sqrt(d), s=0.1, N=%d train, M=%d test, d=%d, fp64" % (n, m, d),
-					   "n": n, "m": m, "d": d, "nb": args.nb or 512,
+					   "n": n, "m": m, "d": d, "nb": args.nb or "potrf 1024, trsm 512 (library defaults)",
 					   "parallelism": "single GPU" if world == 1 else "2-D block-cyclic over %d GPUs" % world},
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),

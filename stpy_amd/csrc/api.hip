@@ -95,7 +95,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, i
 
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
 {
-	if (nb <= 0) nb = 512;
+	if (nb <= 0) nb = POTRF_DEFAULT_NB;
 	return 2 * n * (int64_t)nb * (dtype == STPY_F64 ? 8 : 4);     /* two panel workspaces (look-ahead) */
 }
 

@@ -9,6 +9,7 @@
 namespace stpy {
 
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
+constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
 
 extern int g_gemm_stagger;
 extern int g_gemm_exp;

@@ -12,7 +12,7 @@ namespace stpy {
 template <typename T>
 int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st)
 {
-	if (nb <= 0) nb = 512;
+	if (nb <= 0) nb = TRSM_DEFAULT_NB;
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
 	int rc;
 	for (int64_t k = 0; k < n; k += nb) {
