@@ -54,14 +54,18 @@ const char* stpy_last_error_string(void);
  * cols: device int32[d] column subset ("group", kernels.py:387-388) or NULL for 0..d-1.
  * inv_ls: device array of d elements of `dtype`.  lower_only != 0 writes only i <= j blocks
  * (used when a == b feeds the Cholesky).  diag_add carries s^2 of gauss_procc.py:151-163.
+ * work: NULL, or stpy_gram_workspace_bytes(dtype, n, q, d) bytes of scratch.  With a workspace the
+ * inner products run on the MFMA contraction with the kernel function fused into its epilogue
+ * (all kinds except MATERN12, which always uses the direct-difference tile kernel).
  */
+int64_t stpy_gram_workspace_bytes(int dtype, int64_t n, int64_t q, int d);
 int stpy_gram(int kind, int dtype,
               const void* a, int64_t n, int64_t lda,
               const void* b, int64_t q, int64_t ldb,
               int d, const int32_t* cols, const void* inv_ls,
               double kappa, double offset, double diag_add,
               int lower_only, int combine,
-              void* out, int64_t ldo, void* stream);
+              void* out, int64_t ldo, void* work, void* stream);
 
 /* k(x_i, x_i) for i < m -- replaces the per-point Python loop of gauss_procc.py:347 */
 int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,

@@ -26,7 +26,8 @@ _vp, _i64, _i32, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double
 SIGNATURES = {
 	"stpy_version": (_c.c_char_p, []),
 	"stpy_last_error_string": (_c.c_char_p, []),
-	"stpy_gram": (_i32, [_i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _i32, _i32, _vp, _i64, _vp]),
+	"stpy_gram": (_i32, [_i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _i32, _i32, _vp, _i64, _vp, _vp]),
+	"stpy_gram_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32]),
 	"stpy_gram_diag": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _i32, _vp, _vp]),
 	"stpy_potrf_workspace_bytes": (_i64, [_i32, _i64, _i32]),
 	"stpy_potrf_winv_elems": (_i64, [_i64]),

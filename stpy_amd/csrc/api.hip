@@ -73,14 +73,19 @@ const char* stpy_last_error_string(void) { return g_err; }
 
 int stpy_gram(int kind, int dtype, const void* a, int64_t n, int64_t lda, const void* b, int64_t q, int64_t ldb,
               int d, const int32_t* cols, const void* inv_ls, double kappa, double offset, double diag_add,
-              int lower_only, int combine, void* out, int64_t ldo, void* stream)
+              int lower_only, int combine, void* out, int64_t ldo, void* work, void* stream)
 {
 	if (!a || !b || !out || !inv_ls) { set_error("stpy_gram: null pointer"); return -3; }
 	if (d <= 0 || lda < 1 || ldb < 1 || ldo < n) { set_error("stpy_gram: bad dimensions d=%d ldo=%lld n=%lld", d, (long long)ldo, (long long)n); return -9; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         gram<double>(kind, (const double*)a, n, lda, (const double*)b, q, ldb, d, cols, (const double*)inv_ls, kappa, offset, diag_add, lower_only, combine, (double*)out, ldo, st),
-	         gram<float>(kind, (const float*)a, n, lda, (const float*)b, q, ldb, d, cols, (const float*)inv_ls, kappa, offset, diag_add, lower_only, combine, (float*)out, ldo, st));
+	         gram<double>(kind, (const double*)a, n, lda, (const double*)b, q, ldb, d, cols, (const double*)inv_ls, kappa, offset, diag_add, lower_only, combine, (double*)out, ldo, work, st),
+	         gram<float>(kind, (const float*)a, n, lda, (const float*)b, q, ldb, d, cols, (const float*)inv_ls, kappa, offset, diag_add, lower_only, combine, (float*)out, ldo, work, st));
+}
+
+int64_t stpy_gram_workspace_bytes(int dtype, int64_t n, int64_t q, int d)
+{
+	return gram_workspace_bytes(n, q, d, dtype == STPY_F64 ? 8 : 4);
 }
 
 int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,

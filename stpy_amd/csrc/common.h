@@ -51,10 +51,11 @@ template <> struct Mfma<float> {
 // ---- internal launchers (all enqueue on `st`, return 0 or a negative error code) ----
 struct BlockCyclic { int nb_dist, pr, pc, myr, myc, i0, j0; };
 template <typename T> struct RffEpilogue { int half; T scale; const T* bias; };
+template <typename T> struct GramEpilogue { int kind, combine; T kappa, offset, diag_add; const T* na; const T* nb; };
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
-            const RffEpilogue<T>* rff = nullptr);
+            const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr);
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st);
 template <typename T>
@@ -72,7 +73,8 @@ int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st);
 template <typename T>
 int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, int64_t ldb, int d,
          const int32_t* cols, const T* inv_ls, double kappa, double offset, double diag_add,
-         int lower_only, int combine, T* out, int64_t ldo, hipStream_t st);
+         int lower_only, int combine, T* out, int64_t ldo, void* work, hipStream_t st);
+int64_t gram_workspace_bytes(int64_t n, int64_t q, int d, size_t esz);
 template <typename T>
 int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t* cols, const T* inv_ls,
               double kappa, double offset, int combine, T* out, hipStream_t st);

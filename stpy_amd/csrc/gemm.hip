@@ -45,6 +45,10 @@ struct GemmArgs {
 	int epi_half;            // mode 2: columns < epi_half take cos, the rest sin (all cos when epi_bias != null)
 	T epi_scale;             // mode 2: output scale sqrt(2/m) sqrt(kappa)
 	const T* epi_bias;       // mode 2: optional phase per column
+	// mode 3: Gram epilogue  C[j][i] (op)= kappa * phi(nb[j] + na[i] - 2 acc) (+ offset) + diag_add [i == j]
+	const T* g_na; const T* g_nb;
+	T g_kappa, g_offset, g_diag;
+	int g_kind, g_combine;
 	int tri;                 // 1: lower-triangular tile set (square C), super-tiles enumerated over the lower triangle
 	int stagger;             // >0: first-round workgroups in the odd wave slot of their SIMD start this many cycles late
 	// block-cyclic "staircase" (multi-GPU local trailing update): C is a window of a rank's local
@@ -69,6 +73,44 @@ template <> __device__ __forceinline__ float rff_value<float>(float q, bool use_
 	float t = q * 0.15915494309189535f;
 	t -= rintf(t);
 	return scale * (use_cos ? __builtin_amdgcn_cosf(t) : __builtin_amdgcn_sinf(t));
+}
+
+// exp(x) for the Gram epilogue, x <= ~0.  Written out (no libm call): 2^k * p(r), r = x - k ln2 in
+// two steps, degree-13 Taylor on |r| <= 0.347 (remainder 4e-18), v_ldexp for the scaling; ~20
+// instructions, no branches, <= 2 ulp -- small enough that the epilogue loops below stay unrolled.
+__device__ __forceinline__ double gram_exp(double x)
+{
+	x = fmax(x, -745.0);
+	const double k = rint(x * 1.4426950408889634074);
+	double r = fma(-k, 6.93147180369123816490e-01, x);
+	r = fma(-k, 1.90821492927058770002e-10, r);
+	double p = 1.6059043836821613e-10;                 // 1/13!
+	p = fma(p, r, 2.08767569878681e-09);               // 1/12!
+	p = fma(p, r, 2.505210838544172e-08);              // 1/11!
+	p = fma(p, r, 2.755731922398589e-07);              // 1/10!
+	p = fma(p, r, 2.7557319223985893e-06);             // 1/9!
+	p = fma(p, r, 2.48015873015873e-05);               // 1/8!
+	p = fma(p, r, 1.984126984126984e-04);              // 1/7!
+	p = fma(p, r, 1.388888888888889e-03);              // 1/6!
+	p = fma(p, r, 8.333333333333333e-03);              // 1/5!
+	p = fma(p, r, 4.1666666666666664e-02);             // 1/4!
+	p = fma(p, r, 1.6666666666666666e-01);             // 1/3!
+	p = fma(p, r, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	return ldexp(p, (int)k);
+}
+__device__ __forceinline__ float gram_exp(float x) { return __expf(x); }
+
+template <typename T, int KIND> __device__ __forceinline__ T gram_value(T acc, T na, T nb)
+{
+	if (KIND == STPY_K_LINEAR) return acc;
+	const T sq = na + nb - T(2) * acc;
+	if (KIND == STPY_K_SE) return gram_exp(T(-0.5) * sq);           // no clamp, as kernels.py:395
+	const T rr = sqrt(fmax(sq, T(0)));
+	if (KIND == STPY_K_MATERN32) { const T r = rr * T(1.7320508075688772935); return (T(1) + r) * gram_exp(-r); }
+	const T r = rr * T(2.2360679774997896964);                       // MATERN52
+	return (T(1) + r + r * r * T(0.33333333333333333333)) * gram_exp(-r);
 }
 
 template <typename T, bool GUARD, bool SUB>
@@ -296,6 +338,67 @@ void gemm_nt_kernel(GemmArgs<T> p)
 					acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + bias[tn], use_cos[tn], p.epi_scale);
 	}
 
+	// ---- fused Gram epilogue (mode 3): norms of the (pre-scaled) points come from the workspace.
+	// The kernel family is dispatched ONCE around straight-line loops (a per-element switch made
+	// the epilogue 130 KB of branchy code that no longer fit the instruction cache); the kernel
+	// algebra (+, *) and the diagonal term are separate, rarely taken passes.
+	if (!SUB && p.mode == 3) {
+		// the tile's 128 + 128 norms go through LDS (the staging buffers are free after the K loop):
+		// holding them in registers next to the accumulators does not fit
+		T* const ns = smem;
+		if (tid < BN) { const int col = col0 + tid; ns[tid] = p.g_na[GUARD ? min(col, p.n - 1) : col]; }
+		else { const int row = row0 + tid - BN; ns[tid] = p.g_nb[GUARD ? min(row, p.m - 1) : row]; }
+		__syncthreads();
+		T na4[4];
+#pragma unroll
+		for (int tn = 0; tn < 4; ++tn) na4[tn] = ns[wn * 64 + r16 + tn * 16];
+		auto apply = [&](auto KC) {
+			constexpr int KIND = decltype(KC)::value;
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+						acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)]) + p.g_offset;
+					// four independent exp chains at a time are enough to cover the FMA latency; letting
+					// the scheduler interleave all 64 costs >250 spilled VGPRs
+					__builtin_amdgcn_sched_barrier(0);
+				}
+		};
+		switch (p.g_kind) {
+		case STPY_K_SE: apply(std::integral_constant<int, STPY_K_SE>{}); break;
+		case STPY_K_MATERN32: apply(std::integral_constant<int, STPY_K_MATERN32>{}); break;
+		case STPY_K_MATERN52: apply(std::integral_constant<int, STPY_K_MATERN52>{}); break;
+		default: apply(std::integral_constant<int, STPY_K_LINEAR>{}); break;
+		}
+		if (p.g_combine != STPY_OUT_SET) {
+			const bool add = p.g_combine == STPY_OUT_ADD;
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+					const int lrc = GUARD ? min(lr, p.m - 1 - row0) : lr;
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn) {
+						const int lc = wn * 64 + r16 + tn * 16;
+						const T old = ctile[(unsigned)lrc * ldc32 + (unsigned)(GUARD ? min(lc, p.n - 1 - col0) : lc)];
+						acc[tm][tn][i] = add ? old + acc[tm][tn][i] : old * acc[tm][tn][i];
+					}
+				}
+		}
+		if (p.g_diag != T(0) && row0 == col0) {         // tiles are 128-aligned: only diagonal tiles hold i == j
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+						if (wm * 64 + tm * 16 + MM::crow(lane, i) == wn * 64 + r16 + tn * 16) acc[tm][tn][i] += p.g_diag;
+		}
+	}
+
 	// ---- epilogue: reg i of tile (tm,tn) is C[row0 + wm*64 + tm*16 + crow(lane,i)][col0 + wn*64 + tn*16 + r16]
 	const unsigned ldc2_32 = (unsigned)p.ldc2;
 #pragma unroll
@@ -330,7 +433,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
-            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc, const RffEpilogue<T>* rff)
+            T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc, const RffEpilogue<T>* rff,
+            const GramEpilogue<T>* gr)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (k <= 0) {
@@ -349,6 +453,12 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	if (mode == 2) {
 		if (!rff || sizeof(T) != 4) { set_error("gemm_nt: mode 2 (fused RFF epilogue) is fp32 only and needs its parameters"); return -12; }
 		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias;
+	}
+	p.g_na = p.g_nb = nullptr; p.g_kappa = T(1); p.g_offset = p.g_diag = T(0); p.g_kind = 0; p.g_combine = 0;
+	if (mode == 3) {
+		if (!gr) { set_error("gemm_nt: mode 3 needs the Gram epilogue parameters"); return -12; }
+		p.g_na = gr->na; p.g_nb = gr->nb; p.g_kappa = gr->kappa; p.g_offset = gr->offset; p.g_diag = gr->diag_add;
+		p.g_kind = gr->kind; p.g_combine = gr->combine;
 	}
 	p.exp = g_gemm_exp;
 	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
@@ -390,7 +500,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	return check_launch("gemm_nt");
 }
 
-template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*);
-template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*);
+template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*, const GramEpilogue<double>*);
+template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*, const GramEpilogue<float>*);
 
 }  // namespace stpy

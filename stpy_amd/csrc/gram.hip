@@ -145,12 +145,63 @@ void gram_kernel(GramArgs<T> p)
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA route (SE / ARD, Matern 3/2 and 5/2, linear).  <b_j, a_i> over the d scaled coordinates is an
+// NT contraction, so it runs on the GEMM of gemm.hip with the kernel function fused into its store
+// epilogue: the fp64 vector ALU -- the bottleneck of the tile kernel above, which needs ~60
+// instructions per element -- is left with the ~25 of the exp.  The points are first gathered
+// (column subset), scaled by the inverse lengthscales and zero-padded to a multiple of 16
+// coordinates into the caller's workspace, together with their squared norms.
+// Matern 1/2 keeps the direct-difference tile kernel: exp(-r) has a first-order term in r, and
+// r from the norm expansion is only good to ~1e-8 on coincident points.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void prep_points_kernel(const T* __restrict__ x, int64_t n, int64_t ldx, int d, int dpad, const int32_t* cols, const T* __restrict__ inv_ls,
+                        T* __restrict__ xs, T* __restrict__ nx)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	T s = T(0);
+	for (int k = 0; k < dpad; ++k) {
+		T v = T(0);
+		if (k < d) v = x[i * ldx + (cols ? cols[k] : k)] * inv_ls[k];
+		xs[i * dpad + k] = v;
+		s += v * v;
+	}
+	nx[i] = s;
+}
+
+static inline int64_t align16(int64_t b) { return (b + 15) & ~(int64_t)15; }
+
+int64_t gram_workspace_bytes(int64_t n, int64_t q, int d, size_t esz)
+{
+	const int64_t dpad = (d + 15) / 16 * 16;
+	return align16(n * dpad * esz) + align16(q * dpad * esz) + align16(n * esz) + align16(q * esz);
+}
+
 template <typename T>
 int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, int64_t ldb, int d,
          const int32_t* cols, const T* inv_ls, double kappa, double offset, double diag_add,
-         int lower_only, int combine, T* out, int64_t ldo, hipStream_t st)
+         int lower_only, int combine, T* out, int64_t ldo, void* work, hipStream_t st)
 {
 	if (n <= 0 || q <= 0) return 0;
+	if (work && kind != STPY_K_MATERN12 && kind >= STPY_K_SE && kind <= STPY_K_LINEAR) {
+		const int dpad = (d + 15) / 16 * 16;
+		char* w = (char*)work;
+		T* as = (T*)w; w += align16(n * (int64_t)dpad * sizeof(T));
+		T* bs = (T*)w; w += align16(q * (int64_t)dpad * sizeof(T));
+		T* na = (T*)w; w += align16(n * sizeof(T));
+		T* nb = (T*)w;
+		const bool same = (a == b) && (n == q) && (lda == ldb);
+		hipLaunchKernelGGL((prep_points_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, n, lda, d, dpad, cols, inv_ls, as, na);
+		if (same) { bs = as; nb = na; }
+		else hipLaunchKernelGGL((prep_points_kernel<T>), dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, b, q, ldb, d, dpad, cols, inv_ls, bs, nb);
+		int rc = check_launch("gram prep");
+		if (rc) return rc;
+		GramEpilogue<T> epi{kind, combine, (T)kappa, (T)(kind == STPY_K_LINEAR ? offset : 0.0), (T)diag_add, na, nb};
+		return gemm_nt<T>(q, n, dpad, bs, dpad, as, dpad, out, ldo, (T*)nullptr, 0, 3, lower_only, st, nullptr, nullptr, &epi);
+	}
 	if (n > INT32_MAX || q > INT32_MAX) { set_error("gram: dimension exceeds int32"); return -4; }
 	if (kind < STPY_K_SE || kind > STPY_K_LINEAR) { set_error("gram: unknown kernel kind %d", kind); return -1; }
 	GramArgs<T> p;
@@ -199,7 +250,7 @@ int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t
 }
 
 #define INST(T) \
-	template int gram<T>(int, const T*, int64_t, int64_t, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, double, int, int, T*, int64_t, hipStream_t); \
+	template int gram<T>(int, const T*, int64_t, int64_t, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, double, int, int, T*, int64_t, void*, hipStream_t); \
 	template int gram_diag<T>(int, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, int, T*, hipStream_t);
 INST(double)
 INST(float)

@@ -217,6 +217,8 @@ class KernelFunction:
 		items = self._resolve(dict(kwargs) if kwargs else {})
 		dt = _lib.dtype_code(out.dtype)
 		n, q = a.shape[0], b.shape[0]
+		dmax = max(len(it['group']) for it in items)
+		work = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, q, dmax)),), dtype=torch.uint8, device=out.device)
 		for idx, it in enumerate(items):
 			group = it['group']
 			identity = (group == list(range(a.shape[1])))
@@ -227,7 +229,7 @@ class KernelFunction:
 			rc = lib.stpy_gram(it['kind'], dt, _lib.ptr(a), n, a.stride(0), _lib.ptr(b), q, b.stride(0),
 							   len(group), _lib.ptr(cols), _lib.ptr(inv_ls), it['kappa'], it['offset'],
 							   diag_add if last else 0.0, 1 if lower_only else 0, combine,
-							   _lib.ptr(out), out.stride(0), _lib.stream_ptr())
+							   _lib.ptr(out), out.stride(0), _lib.ptr(work), _lib.stream_ptr())
 			_lib.check(rc, "stpy_gram")
 		return out
 

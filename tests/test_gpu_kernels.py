@@ -122,9 +122,18 @@ def oracle_gram(kind, a, b, inv_ls, kappa, offset, cols):
 	return O.linear(a, b, kappa, offset, group)
 
 
+def workspace(L, n, q, d, dtype=torch.float64):
+	lib = L.load()
+	return torch.empty((int(lib.stpy_gram_workspace_bytes(L.dtype_code(dtype), n, q, d)),), dtype=torch.uint8, device="cuda:0")
+
+
+@pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("name,kind", KINDS)
-@pytest.mark.parametrize("n,q,d", [(5, 7, 3), (128, 64, 16), (300, 131, 1), (257, 513, 33)])
-def test_gram_kinds(L, name, kind, n, q, d):
+@pytest.mark.parametrize("n,q,d", [(5, 7, 3), (128, 64, 16), (300, 131, 1), (257, 513, 33), (256, 384, 16)])
+def test_gram_kinds(L, name, kind, n, q, d, use_ws):
+	"""use_ws=False: direct tile kernel; True: MFMA contraction + fused epilogue (not for Matern 1/2)"""
+	ws = workspace(L, n, q, d) if use_ws else None
+	WORK = L.ptr(ws)
 	rng = np.random.RandomState(n + q + d + kind)
 	a, b = rng.uniform(-1, 1, size=(n, d)), rng.uniform(-1, 1, size=(q, d))
 	inv_ls = rng.uniform(0.3, 1.5, size=d) if kind != 4 else np.ones(d)
@@ -132,15 +141,18 @@ def test_gram_kinds(L, name, kind, n, q, d):
 	out = torch.empty((q, n), dtype=torch.float64, device="cuda:0")
 	lib = L.load()
 	L.check(lib.stpy_gram(kind, L.F64, L.ptr(ad), n, d, L.ptr(bd), q, d, d, None, L.ptr(ild), 1.3, 0.25, 0.0, 0, 0,
-						  L.ptr(out), n, L.stream_ptr()), "gram")
+						  L.ptr(out), n, WORK, L.stream_ptr()), "gram")
 	ref = oracle_gram(kind, a, b, inv_ls, 1.3, 0.25, None)
 	assert out.shape == (q, n)
 	assert rel_err(out.cpu().numpy(), ref) < 1e-13
 
 
-def test_gram_cols_combine_diag_lower(L):
+@pytest.mark.parametrize("use_ws", [False, True])
+def test_gram_cols_combine_diag_lower(L, use_ws):
 	rng = np.random.RandomState(3)
 	n, d = 333, 6
+	ws = workspace(L, n, n, d) if use_ws else None
+	WORK = L.ptr(ws)
 	x = rng.uniform(-1, 1, size=(n, d))
 	xd = dev(x)
 	cols = [0, 2, 5]
@@ -150,19 +162,19 @@ def test_gram_cols_combine_diag_lower(L):
 	out = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
 	ild, il2d = dev(inv_ls), dev(np.full(d, 0.7))
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(ild), 1.1, 0.0, 0.0, 0, L.OUT_SET,
-						  L.ptr(out), n, L.stream_ptr()), "gram")
+						  L.ptr(out), n, WORK, L.stream_ptr()), "gram")
 	k1 = oracle_gram(0, x, x, inv_ls, 1.1, 0.0, cols)
 	assert rel_err(out.cpu().numpy(), k1) < 1e-13
 	# product with a Matern 5/2 on all columns, then diag_add on the last item
 	il2 = np.full(d, 0.7)
 	L.check(lib.stpy_gram(3, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, d, None, L.ptr(il2d), 0.9, 0.0, 0.04, 0, L.OUT_MUL,
-						  L.ptr(out), n, L.stream_ptr()), "gram")
+						  L.ptr(out), n, WORK, L.stream_ptr()), "gram")
 	k2 = k1 * oracle_gram(3, x, x, il2, 0.9, 0.0, None) + 0.04 * np.eye(n)
 	assert rel_err(out.cpu().numpy(), k2) < 1e-13
 	# lower_only: lower triangle identical, sum with ADD
 	out2 = torch.full((n, n), 7.0, dtype=torch.float64, device="cuda:0")
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(ild), 1.1, 0.0, 0.5, 1, L.OUT_SET,
-						  L.ptr(out2), n, L.stream_ptr()), "gram")
+						  L.ptr(out2), n, WORK, L.stream_ptr()), "gram")
 	o2 = out2.cpu().numpy()
 	il = np.tril_indices(n)
 	assert rel_err(o2[il], (k1 + 0.5 * np.eye(n))[il]) < 1e-13
@@ -321,7 +333,8 @@ def test_rff_f32(L):
 
 def test_error_reporting(L):
 	lib = L.load()
-	rc = lib.stpy_gram(99, L.F64, None, 1, 1, None, 1, 1, 1, None, None, 1.0, 0.0, 0.0, 0, 0, None, 1, L.stream_ptr())
+	WORK = None
+	rc = lib.stpy_gram(99, L.F64, None, 1, 1, None, 1, 1, 1, None, None, 1.0, 0.0, 0.0, 0, 0, None, 1, WORK, L.stream_ptr())
 	assert rc < 0 and b"null" in lib.stpy_last_error_string()
 	x = dev(np.zeros((2, 2)))
 	rc = lib.stpy_gemm_nt(7, 2, 2, 2, L.ptr(x), 2, L.ptr(x), 2, L.ptr(x), 2, 0, 0, L.stream_ptr())

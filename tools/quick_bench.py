@@ -43,9 +43,12 @@ def bench_potrf(n, nb):
 	winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device=dev)
 	work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), dtype=torch.uint8, device=dev)
 	info = torch.zeros(1, dtype=torch.int32, device=dev)
-	gram = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.stream_ptr()), "gram")
+	ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, 16)), dtype=torch.uint8, device=dev)
+	gram0 = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, None, L.stream_ptr()), "gram")
+	gram = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), L.stream_ptr()), "gram")
+	t0, _ = timeit(gram0)
 	t, _ = timeit(gram)
-	print("gram lower n=%d: %.3f ms  %.2f TB/s" % (n, t * 1e3, n * n * 8 * 0.5 / t / 1e12), flush=True)
+	print("gram lower n=%d: tile kernel %.3f ms %.2f TB/s | MFMA+epilogue %.3f ms  %.2f TB/s" % (n, t0 * 1e3, n * n * 8 * 0.5 / t0 / 1e12, t * 1e3, n * n * 8 * 0.5 / t / 1e12), flush=True)
 	def f():
 		gram()
 		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), nb, L.ptr(info), L.stream_ptr()), "potrf")
