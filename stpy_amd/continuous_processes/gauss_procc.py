@@ -82,7 +82,7 @@ class GaussianProcess:
 		self._winv = None       # inverse 128 x 128 diagonal blocks of L
 		self._z = None          # L^-1 y
 		self._Sigma = None
-		self.A = None           # K^-1 y  (gauss_procc.py:376), (N, 1)
+		self._alpha_cache = None
 
 	# ------------------------------------------------------------------ small API mirrors
 	def description(self):
@@ -152,18 +152,36 @@ class GaussianProcess:
 			raise torch.linalg.LinAlgError("stpy_potrf: the leading minor of order %d of K + s^2 I is not positive definite" % bad)
 		return K, winv
 
-	def _solve_y(self, L, winv, yd):
-		"""z = L^-1 y, alpha = L^-T z."""
+	def _forward_y(self, L, winv, yd):
+		"""z = L^-1 y."""
 		lib = _lib.load()
-		n = L.shape[0]
-		dt = _lib.dtype_code(L.dtype)
 		scratch = yd.reshape(-1).clone()
 		z = torch.empty_like(scratch)
-		_lib.check(lib.stpy_trsv(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(z), 0, _lib.stream_ptr()), "stpy_trsv")
-		scratch.copy_(z)
+		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(z), 0,
+								 _lib.stream_ptr()), "stpy_trsv")
+		return z
+
+	def _backward_z(self, L, winv, z):
+		"""alpha = L^-T z."""
+		lib = _lib.load()
+		scratch = z.clone()
 		alpha = torch.empty_like(scratch)
-		_lib.check(lib.stpy_trsv(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(alpha), 1, _lib.stream_ptr()), "stpy_trsv")
-		return z, alpha
+		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(alpha), 1,
+								 _lib.stream_ptr()), "stpy_trsv")
+		return alpha
+
+	@property
+	def _alpha(self):
+		"""K^-1 y = L^-T z on the device (filled by fit_gp)."""
+		if self._alpha_cache is None and self.fitted:
+			self._alpha_cache = self._backward_z(self._L, self._winv, self._z)
+		return self._alpha_cache
+
+	@property
+	def A(self):
+		"""K^-1 y, (N, 1)  (gauss_procc.py:376)."""
+		a = self._alpha
+		return None if a is None else _lib.like_input(a.reshape(-1, 1), self.x)
 
 	def fit_gp(self, x, y, Sigma=None, iterative=False, extrapoint=False):
 		"""gauss_procc.py:136-177 (the ``iterative`` branch of the reference is a stub and is ignored)."""
@@ -176,11 +194,12 @@ class GaussianProcess:
 		self._Sigma = Sigma
 		self._xd = _lib.to_device(x)
 		self._yd = _lib.to_device(y, self._xd.dtype).reshape(-1, 1)
-		self._L = self._winv = self._z = None       # release the previous factor before allocating the next
+		self._L = self._winv = self._z = self._alpha_cache = None       # release the previous factor before allocating the next
 		self._L, self._winv = self._factor(self._xd, None, Sigma)
-		self._z, alpha = self._solve_y(self._L, self._winv, self._yd)
-		self.A = _lib.like_input(alpha.reshape(-1, 1), x)
-		self._alpha = alpha
+		self._z = self._forward_y(self._L, self._winv, self._yd)
+		# A = K^-1 y is part of the fitted state the reference leaves behind (gauss_procc.py:376): computed
+		# eagerly even though mean_std itself only needs z
+		self._alpha_cache = self._backward_z(self._L, self._winv, self._z)
 		self.fitted = True
 		return None
 
@@ -320,7 +339,7 @@ class GaussianProcess:
 				L, winv = self._factor(self._xd, X, None)
 			finally:
 				self.kernel_object = saved
-			z, _ = self._solve_y(L, winv, self._yd)
+			z = self._forward_y(L, winv, self._yd)
 		out2 = torch.empty((2,), dtype=L.dtype, device=L.device)
 		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(z), _lib.ptr(out2),
 										_lib.stream_ptr()), "stpy_logdet_quad")
