@@ -313,6 +313,50 @@ class GaussianProcess:
 									_lib.ptr(mu), None, 0, _lib.stream_ptr()), "stpy_predict")
 		return _lib.like_input(mu.reshape(-1, 1), xtest)
 
+	# ------------------------------------------------------------------ sampling
+	def sample(self, xtest, size=1, jitter=10e-8):
+		"""
+		gauss_procc.py:461-482: f = mean + chol(Cov + 1e-9 I) r  (posterior, full covariance) or
+		mu + chol(K** + jitter I) r (prior).  The standard-normal draws are taken exactly as in the
+		reference -- torch.normal on the CPU generator, shape (nn, size) -- so a seeded reference run
+		and a seeded run here see the same random_vector; the M x M Cholesky and the product run in
+		stpy_potrf / stpy_gemm_nt.
+		"""
+		lib = _lib.load()
+		nn = list(xtest.size())[0]
+		if self.fitted == True:
+			(ymean, cov) = self.mean_std(xtest, full=True)
+			eps = 10e-10
+		else:
+			(_, cov) = self.execute(xtest)
+			ymean = self.mu
+			eps = jitter
+		C = _lib.to_device(cov).clone()
+		C.diagonal().add_(eps)
+		dt = _lib.dtype_code(C.dtype)
+		winv = torch.empty((int(lib.stpy_potrf_winv_elems(nn)),), dtype=C.dtype, device=C.device)
+		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, nn, self.nb)),), dtype=torch.uint8, device=C.device)
+		info = torch.zeros((1,), dtype=torch.int32, device=C.device)
+		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), C.stride(0), _lib.ptr(winv), _lib.ptr(work), self.nb, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
+		bad = int(info.item())
+		if bad != 0:
+			raise torch.linalg.LinAlgError("sample: posterior covariance + jitter is not positive definite (leading minor %d)" % bad)
+		C.tril_()                                    # the strict upper triangle of an in-place factor is scratch
+		random_vector = torch.normal(mean=torch.zeros(nn, size, dtype=torch.float64), std=1.)
+		rt = random_vector.T.contiguous().to(device=C.device, dtype=C.dtype)          # (size, nn): the NT operand
+		f = torch.empty((nn, size), dtype=C.dtype, device=C.device)
+		_lib.check(lib.stpy_gemm_nt(dt, nn, size, nn, _lib.ptr(C), C.stride(0), _lib.ptr(rt), rt.stride(0), _lib.ptr(f), f.stride(0), 0, 0,
+									_lib.stream_ptr()), "stpy_gemm_nt")
+		f = _lib.like_input(f, xtest)
+		return ymean + f
+
+	def sample_and_max(self, xtest, size=1):
+		"""gauss_procc.py:484-494."""
+		f = self.sample(xtest, size=size)
+		self.temp = f
+		val, index = torch.max(f, dim=0)
+		return (xtest[index, :], val)
+
 	# ------------------------------------------------------------------ evidence
 	def log_marginal(self, kernel, X, weight):
 		"""

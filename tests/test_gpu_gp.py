@@ -261,6 +261,31 @@ def test_G11_lu_branch_and_helpers(S):
 	assert np.array_equal(helper.cartesian([np.array([1., 2.]), np.array([3., 4., 5.])]), h["cartesian_2x3"])
 
 
+def test_sample_matches_seeded_reference_formula(S):
+	"""gauss_procc.py:461-482 with the same CPU-generator draws (torch.manual_seed): posterior and prior paths."""
+	g = golden("G7_full_prior")
+	xt = T(g["xtest"])
+	nn = xt.shape[0]
+	GP = S.GaussianProcess(gamma=0.6, s=0.1, kappa=1.4, kernel_name="squared_exponential", d=2)
+	torch.manual_seed(7)
+	f0 = GP.sample(xt, size=3)
+	torch.manual_seed(7)
+	rv = torch.normal(mean=torch.zeros(nn, 3, dtype=torch.float64), std=1.).numpy()
+	L0 = np.linalg.cholesky(g["prior_kss"] + 10e-8 * np.eye(nn))
+	assert tuple(f0.shape) == (nn, 3) and rel_err(N(f0), L0 @ rv) < 1e-6
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	torch.manual_seed(11)
+	f = GP.sample(xt, size=2)
+	torch.manual_seed(11)
+	rv = torch.normal(mean=torch.zeros(nn, 2, dtype=torch.float64), std=1.).numpy()
+	Lc = np.linalg.cholesky(g["full_cov"] + 10e-10 * np.eye(nn))
+	ref = g["full_mu"] + Lc @ rv
+	# the posterior covariance is nearly singular (jitter 1e-9): Cholesky amplifies 1e-12 differences
+	assert rel_err(N(f), ref) < 1e-4
+	xm, val = GP.sample_and_max(xt, size=2)
+	assert tuple(val.shape) == (2,)
+
+
 def test_not_positive_definite_raises(S):
 	x = torch.zeros((300, 2), dtype=torch.float64)        # 300 identical points, no noise -> singular
 	GP = S.GaussianProcess(gamma=1.0, s=0.0, kappa=1.0, kernel_name="squared_exponential", d=2)
