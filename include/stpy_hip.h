@@ -91,6 +91,24 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* wor
 int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
                        const void* winv, void* B, int64_t ldb, int nb, void* stream);
 
+/*
+ * Gradient of the evidence (estimator.py:156-190 drives it through
+ * autograd in the reference):  d/dtheta [1/2 y^T K^-1 y + w/2 log det K] = 1/2 tr((w K^-1 - alpha alpha^T) dK/dtheta).
+ *
+ * stpy_potri: Kinv (n x n, lower triangle written) <- (L L^T)^-1 from the factor; work: n x n
+ *   elements of scratch (receives L^-T).  2 n^3/3 flop on the MFMA GEMM.
+ * stpy_lml_weight: H <- (weight * H - alpha alpha^T) o F in place, H holding the full symmetric
+ *   K^-1 on entry; F_ij is the factor of d k(x_i,x_j) / d lengthscale_m = F_ij u_m^2 / lengthscale_m
+ *   (u = scaled coordinate difference) for the kernel family `kind` (SE, MATERN12/32/52).
+ *   work: stpy_gram_workspace_bytes(dtype, n, n, d).  The per-coordinate sums sum_ij H_ij u_m^2 then
+ *   follow from H [Xs | 1] (one stpy_gemm_nt) -- see stpy_amd/continuous_processes/gauss_procc.py.
+ */
+int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv,
+               void* Kinv, int64_t ldk, void* work, void* stream);
+int stpy_lml_weight(int kind, int dtype, const void* x, int64_t n, int64_t ldx, int d,
+                    const int32_t* cols, const void* inv_ls, double kappa, double weight,
+                    const void* alpha, void* H, int64_t ldh, void* work, void* stream);
+
 /* out = L^-1 y (trans = 0) or out = L^-T y (trans = 1); the two together are cholesky_solve,
  * estimator.py:37.  y is used as scratch (destroyed); out must not alias y. */
 int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* y,

@@ -33,6 +33,8 @@ SIGNATURES = {
 	"stpy_potrf_winv_elems": (_i64, [_i64]),
 	"stpy_potrf": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
 	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp]),
+	"stpy_potri": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+	"stpy_lml_weight": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp]),
 	"stpy_trsv": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
 	"stpy_predict": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
 	"stpy_logdet_quad": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp]),

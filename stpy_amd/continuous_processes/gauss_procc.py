@@ -34,6 +34,23 @@ from .. import _lib
 from ..kernels import KernelFunction
 
 
+class _LogMarginalFn(torch.autograd.Function):
+	"""Autograd node of GaussianProcess.log_marginal: forward = the HIP evidence, backward = its analytic gradient."""
+
+	@staticmethod
+	def forward(ctx, gp, kernel, X, weight, *tensors):
+		val, state = gp._log_marginal_value(kernel, X, weight)
+		ctx.gp, ctx.kernel, ctx.X, ctx.weight, ctx.state = gp, kernel, X, weight, state
+		ctx.params = gp._grad_params(X)
+		return val.clone()
+
+	@staticmethod
+	def backward(ctx, gout):
+		grads = ctx.gp._log_marginal_grads(ctx.kernel, ctx.X, ctx.weight, ctx.state, ctx.params)
+		scale = gout.reshape(-1)[0]
+		return (None, None, None, None) + tuple(scale.to(g.device) * g for g in grads)
+
+
 class GaussianProcess:
 
 	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", diameter=1.0,
@@ -365,7 +382,31 @@ class GaussianProcess:
 		Negative log evidence without the n/2 log(2 pi) constant.  ``X`` holds per-item parameter
 		overrides in the kwargs protocol of kernels.py:138-157.  With X empty and ``kernel`` the
 		fitted kernel object, the resident factor is reused.
+
+		If a lengthscale tensor in ``X`` ('gamma' / 'ard_gamma') or the noise ``self.s`` requires grad --
+		the way Estimator.optimize_params_general drives this method (estimator.py:156-190) -- the
+		result carries an autograd node whose backward is the analytic evidence gradient
+		1/2 tr((w K^-1 - alpha alpha^T) dK/dtheta) evaluated on the device (stpy_potri,
+		stpy_lml_weight, stpy_gemm_nt).
 		"""
+		params = self._grad_params(X)
+		if params:
+			return _LogMarginalFn.apply(self, kernel, X, weight, *[t for (_, _, t) in params])
+		return self._log_marginal_value(kernel, X, weight)[0]
+
+	def _grad_params(self, X):
+		"""(key, name, tensor) for every hyper-parameter tensor that asks for a gradient."""
+		out = []
+		for key in sorted(X.keys()) if X else []:
+			for name in ("gamma", "ard_gamma"):
+				v = X[key].get(name) if isinstance(X[key], dict) else None
+				if torch.is_tensor(v) and v.requires_grad:
+					out.append((key, name, v))
+		if torch.is_tensor(self.s) and self.s.requires_grad:
+			out.append(("likelihood", "sigma", self.s))
+		return out
+
+	def _log_marginal_value(self, kernel, X, weight):
 		lib = _lib.load()
 		if self._xd is None:
 			if self.x is None:
@@ -375,7 +416,7 @@ class GaussianProcess:
 			self.n = self._xd.shape[0]
 		reuse = self.fitted and (not X) and (kernel is self.kernel_object) and self._Sigma is None
 		if reuse:
-			L, z = self._L, self._z
+			L, winv, z = self._L, self._winv, self._z
 		else:
 			saved = self.kernel_object
 			self.kernel_object = kernel
@@ -389,7 +430,60 @@ class GaussianProcess:
 										_lib.stream_ptr()), "stpy_logdet_quad")
 		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
 		val = 0.5 * out2[1] + 0.5 * w * 2.0 * out2[0]
-		return _lib.like_input(val.reshape(1, 1), self.x)
+		return _lib.like_input(val.reshape(1, 1), self.x), (L, winv, z)
+
+	def _log_marginal_grads(self, kernel, X, weight, state, params):
+		"""d/dtheta of the value above for every entry of ``params`` (same order), as CPU/GPU tensors shaped like the parameters."""
+		lib = _lib.load()
+		if kernel.kernel_items != 1:
+			raise NotImplementedError("evidence gradients are provided for single-item kernels (no + / * composites yet)")
+		L, winv, z = state
+		n = L.shape[0]
+		dt = _lib.dtype_code(L.dtype)
+		it = kernel._resolve(dict(X) if X else {})[0]
+		if it['kind'] == _lib.K_LINEAR:
+			raise NotImplementedError("the linear kernel has no lengthscale gradient")
+		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
+		st = _lib.stream_ptr
+		alpha = self._backward_z(L, winv, z)
+		Kinv = torch.empty((n, n), dtype=L.dtype, device=L.device)
+		work = torch.empty((n, n), dtype=L.dtype, device=L.device)
+		_lib.check(lib.stpy_potri(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(work), st()), "stpy_potri")
+		del work
+		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), Kinv.stride(0), st()), "stpy_symmetrize_lower")
+		trace_G = w * Kinv.diagonal().sum() - torch.dot(alpha, alpha)                    # tr(w K^-1 - alpha alpha^T)
+		group = it['group']
+		xd = self._xd
+		identity = (group == list(range(xd.shape[1])))
+		from ..kernels import _dev_const
+		cols = None if identity else _dev_const(group, None, xd.device, int32=True)
+		inv_ls = _dev_const(it['inv_ls'], xd.dtype, xd.device)
+		ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
+		_lib.check(lib.stpy_lml_weight(it['kind'], dt, _lib.ptr(xd), n, xd.stride(0), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
+									   it['kappa'], w, _lib.ptr(alpha), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(ws), st()), "stpy_lml_weight")
+		H = Kinv                                                                          # now (w K^-1 - alpha alpha^T) o kappa F
+		xs = (xd if identity else xd[:, group]) * inv_ls                                  # scaled coordinates (n, dg)
+		dg = xs.shape[1]
+		XT = torch.cat([xs.T, torch.ones((1, n), dtype=xs.dtype, device=xs.device)]).contiguous()      # (dg + 1, n): NT operand
+		P = torch.empty((n, dg + 1), dtype=xs.dtype, device=xs.device)
+		_lib.check(lib.stpy_gemm_nt(dt, n, dg + 1, n, _lib.ptr(H), H.stride(0), _lib.ptr(XT), XT.stride(0), _lib.ptr(P), P.stride(0), 0, 0, st()), "stpy_gemm_nt")
+		h = P[:, dg]
+		# sum_ij H_ij u_m^2 = 2 [ sum_i xs_im^2 h_i - xs_m^T H xs_m ];  d/d(ls_m) = that / (2 ls_m)
+		S = (xs * xs * h.unsqueeze(1)).sum(dim=0) - (xs * P[:, :dg]).sum(dim=0)
+		g_ls = S * inv_ls                                                                  # per coordinate of the group
+		grads = []
+		for (key, name, t) in params:
+			if name == "gamma":
+				g = g_ls.sum().reshape(t.shape if t.dim() > 0 else ())
+			elif name == "ard_gamma":
+				full = torch.zeros(t.numel(), dtype=g_ls.dtype, device=g_ls.device)
+				full[torch.tensor(group, device=g_ls.device)] = g_ls
+				g = full.reshape(t.shape)
+			else:       # noise std: dK/ds = 2 s I
+				sval = float(t.detach().reshape(-1)[0].item())
+				g = (sval * trace_G).reshape(t.shape if t.dim() > 0 else ())
+			grads.append(g.to(device=t.device, dtype=t.dtype))
+		return grads
 
 	def load_data(self, d):
 		"""estimator.py:28-30."""

@@ -126,6 +126,26 @@ int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t l
 	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st));
 }
 
+int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* Kinv, int64_t ldk, void* work, void* stream)
+{
+	if (!L || !winv || !Kinv || !work) { set_error("stpy_potri: null pointer"); return -3; }
+	if (n <= 0 || ldl < n || ldk < n) { set_error("stpy_potri: bad dimensions"); return -2; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         potri_lower<double>(n, (const double*)L, ldl, (const double*)winv, (double*)Kinv, ldk, (double*)work, st),
+	         potri_lower<float>(n, (const float*)L, ldl, (const float*)winv, (float*)Kinv, ldk, (float*)work, st));
+}
+
+int stpy_lml_weight(int kind, int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
+                    double kappa, double weight, const void* alpha, void* H, int64_t ldh, void* work, void* stream)
+{
+	if (!x || !inv_ls || !alpha || !H || !work) { set_error("stpy_lml_weight: null pointer"); return -3; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         lml_weight<double>(kind, (const double*)x, n, ldx, d, cols, (const double*)inv_ls, kappa, weight, (const double*)alpha, (double*)H, ldh, work, st),
+	         lml_weight<float>(kind, (const float*)x, n, ldx, d, cols, (const float*)inv_ls, kappa, weight, (const float*)alpha, (float*)H, ldh, work, st));
+}
+
 int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* y, void* out, int trans, void* stream)
 {
 	if (!L || !winv || !y || !out || y == out) { set_error("stpy_trsv: null or aliased pointer (y is scratch, out must differ)"); return -3; }

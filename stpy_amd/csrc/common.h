@@ -51,7 +51,7 @@ template <> struct Mfma<float> {
 // ---- internal launchers (all enqueue on `st`, return 0 or a negative error code) ----
 struct BlockCyclic { int nb_dist, pr, pc, myr, myc, i0, j0; };
 template <typename T> struct RffEpilogue { int half; T scale; const T* bias; };
-template <typename T> struct GramEpilogue { int kind, combine; T kappa, offset, diag_add; const T* na; const T* nb; };
+template <typename T> struct GramEpilogue { int kind, combine; T kappa, offset, diag_add; const T* na; const T* nb; const T* alpha; T weight; };
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
@@ -61,7 +61,12 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 template <typename T>
 int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st);
 template <typename T>
-int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st);
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false);
+template <typename T>
+int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
+template <typename T>
+int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, double kappa, double weight,
+               const T* alpha, T* H, int64_t ldh, void* work, hipStream_t st);
 template <typename T>
 int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int trans, hipStream_t st);
 template <typename T>

@@ -49,6 +49,10 @@ struct GemmArgs {
 	const T* g_na; const T* g_nb;
 	T g_kappa, g_offset, g_diag;
 	int g_kind, g_combine;
+	// mode 4: evidence-gradient weight, in place over a symmetric K^-1:
+	//   C[j][i] = (g_w * C[j][i] - g_alpha[j] * g_alpha[i]) * F_kind(scaled squared distance)
+	const T* g_alpha; T g_w;
+	int kskip;               // 1: operands are upper triangular (B B^T of an inverse factor): K range of tile row ti starts at its first row
 	int tri;                 // 1: lower-triangular tile set (square C), super-tiles enumerated over the lower triangle
 	int stagger;             // >0: first-round workgroups in the odd wave slot of their SIMD start this many cycles late
 	// block-cyclic "staircase" (multi-GPU local trailing update): C is a window of a rank's local
@@ -113,7 +117,23 @@ template <typename T, int KIND> __device__ __forceinline__ T gram_value(T acc, T
 	return (T(1) + r + r * r * T(0.33333333333333333333)) * gram_exp(-r);
 }
 
-template <typename T, bool GUARD, bool SUB>
+// d k / d(lengthscale_m) = F * u_m^2 / lengthscale_m with u_m the scaled coordinate difference; F per family:
+template <typename T, int KIND> __device__ __forceinline__ T gram_dfactor(T acc, T na, T nb)
+{
+	const T sq = na + nb - T(2) * acc;
+	if (KIND == STPY_K_SE) return gram_exp(T(-0.5) * sq);
+	const T rr = sqrt(fmax(sq, T(0)));
+	if (KIND == STPY_K_MATERN12) return rr > T(0) ? gram_exp(-rr) / rr : T(0);
+	if (KIND == STPY_K_MATERN32) return T(3) * gram_exp(-rr * T(1.7320508075688772935));
+	const T r = rr * T(2.2360679774997896964);                       // MATERN52
+	return T(1.6666666666666666667) * (T(1) + r) * gram_exp(-r);
+}
+
+// EPI selects the fused store epilogue at COMPILE time (0 none, 2 RFF trig, 3 Gram kernel function,
+// 4 evidence-gradient weight): the heavy epilogues must not share an instantiation with the plain
+// contraction -- their code raises register pressure enough to push the accumulators of the whole
+// kernel into scratch.
+template <typename T, bool GUARD, bool SUB, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_nt_kernel(GemmArgs<T> p)
 {
@@ -249,9 +269,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		}
 	}
 
-	const int KT = (p.k + BK - 1) / BK;
-	if (DMA) dma_issue(0, 0);
-	else gload(0);
+	const int kbeg = p.kskip ? row0 : 0;        // (multiple of the tile size, so K tiles stay aligned)
+	const int KT = (p.k - kbeg + BK - 1) / BK;
+	if (DMA) dma_issue(0, kbeg);
+	else gload(kbeg);
 
 	// ---- accumulators: zero, or the C tile itself when subtracting (its load overlaps the first
 	// ---- operand tile's; the epilogue is then store-only)
@@ -285,8 +306,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	int buf = 0;
 	for (int kt = 0; kt < KT; ++kt) {
 		if (kt + 1 < KT && !(p.exp & 1)) {
-			if (DMA) dma_issue(buf ^ 1, (kt + 1) * BK);
-			else gload((kt + 1) * BK);
+			if (DMA) dma_issue(buf ^ 1, kbeg + (kt + 1) * BK);
+			else gload(kbeg + (kt + 1) * BK);
 		}
 		const T* as = As + (buf * BM + wm * 64 + r16) * RLD + (DMA ? 0 : g * 4);
 		const T* bs = Bs + (buf * BN + wn * 64 + r16) * RLD + (DMA ? 0 : g * 4);
@@ -320,7 +341,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// fp32 only: the fp64 libm sin/cos bodies are so large that hipcc stops unrolling the loops below,
 	// indexes `acc` at run time and moves ALL accumulators to scratch -- for every use of the
 	// kernel, 5x slower (guide rule 20).  fp64 embeds take the unfused route in rff.hip instead.
-	if (!SUB && sizeof(T) == 4 && p.mode == 2) {
+	if constexpr (EPI == 2) {
 		T bias[4];
 		bool use_cos[4];
 #pragma unroll
@@ -342,7 +363,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// The kernel family is dispatched ONCE around straight-line loops (a per-element switch made
 	// the epilogue 130 KB of branchy code that no longer fit the instruction cache); the kernel
 	// algebra (+, *) and the diagonal term are separate, rarely taken passes.
-	if (!SUB && p.mode == 3) {
+	if constexpr (EPI == 3) {
 		// the tile's 128 + 128 norms go through LDS (the staging buffers are free after the K loop):
 		// holding them in registers next to the accumulators does not fit
 		T* const ns = smem;
@@ -396,6 +417,57 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 					for (int i = 0; i < 4; ++i)
 						if (wm * 64 + tm * 16 + MM::crow(lane, i) == wn * 64 + r16 + tn * 16) acc[tm][tn][i] += p.g_diag;
+		}
+	}
+
+	// ---- evidence-gradient weight (mode 4): H = (w K^-1 - alpha alpha^T) o F, in place over K^-1
+	if constexpr (EPI == 4) {
+		T* const ns = smem;
+		if (tid < BN) { const int col = col0 + tid; ns[tid] = p.g_na[GUARD ? min(col, p.n - 1) : col]; ns[2 * BN + tid] = p.g_alpha[GUARD ? min(col, p.n - 1) : col]; }
+		else { const int row = row0 + tid - BN; ns[tid] = p.g_nb[GUARD ? min(row, p.m - 1) : row]; ns[2 * BN + tid] = p.g_alpha[GUARD ? min(row, p.m - 1) : row]; }
+		__syncthreads();
+		// pass 1: acc <- kappa * F (pure arithmetic, four exp chains at a time)
+		auto apply = [&](auto KC) {
+			constexpr int KIND = decltype(KC)::value;
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn)
+						acc[tm][tn][i] = p.g_kappa * gram_dfactor<T, KIND>(acc[tm][tn][i], ns[wn * 64 + r16 + tn * 16], ns[BN + lr]);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+		};
+		switch (p.g_kind) {
+		case STPY_K_SE: apply(std::integral_constant<int, STPY_K_SE>{}); break;
+		case STPY_K_MATERN12: apply(std::integral_constant<int, STPY_K_MATERN12>{}); break;
+		case STPY_K_MATERN32: apply(std::integral_constant<int, STPY_K_MATERN32>{}); break;
+		default: apply(std::integral_constant<int, STPY_K_MATERN52>{}); break;
+		}
+		// pass 2: acc <- (w * Kinv - alpha_j alpha_i) * acc, the Kinv tile read 16 values at a time
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm) {
+			T old[4][4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+				const int lrc = GUARD ? min(lr, p.m - 1 - row0) : lr;
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) {
+					const int lc = wn * 64 + r16 + tn * 16;
+					old[tn][i] = ctile[(unsigned)lrc * ldc32 + (unsigned)(GUARD ? min(lc, p.n - 1 - col0) : lc)];
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn)
+					acc[tm][tn][i] *= p.g_w * old[tn][i] - ns[3 * BN + lr] * ns[2 * BN + wn * 64 + r16 + tn * 16];
+			}
+			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
 
@@ -455,10 +527,16 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias;
 	}
 	p.g_na = p.g_nb = nullptr; p.g_kappa = T(1); p.g_offset = p.g_diag = T(0); p.g_kind = 0; p.g_combine = 0;
-	if (mode == 3) {
-		if (!gr) { set_error("gemm_nt: mode 3 needs the Gram epilogue parameters"); return -12; }
+	p.g_alpha = nullptr; p.g_w = T(1); p.kskip = 0;
+	if (mode == 3 || mode == 4) {
+		if (!gr) { set_error("gemm_nt: modes 3/4 need the Gram epilogue parameters"); return -12; }
 		p.g_na = gr->na; p.g_nb = gr->nb; p.g_kappa = gr->kappa; p.g_offset = gr->offset; p.g_diag = gr->diag_add;
-		p.g_kind = gr->kind; p.g_combine = gr->combine;
+		p.g_kind = gr->kind; p.g_combine = gr->combine; p.g_alpha = gr->alpha; p.g_w = gr->weight;
+		if (mode == 4 && !gr->alpha) { set_error("gemm_nt: mode 4 needs alpha"); return -12; }
+	}
+	if (lower_only == 2) {          // lower tiles + upper-triangular operands (K range starts at the tile's first row)
+		if (m != n || m % BM != 0 && false) { set_error("gemm_nt: kskip needs a square problem"); return -12; }
+		p.kskip = 1;
 	}
 	p.exp = g_gemm_exp;
 	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
@@ -493,10 +571,16 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	const bool aligned = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && (lda % CH == 0) && (ldb % CH == 0) &&
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
-	if (aligned && mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, false, true>), grid, block, 0, st, p);
-	else if (aligned) hipLaunchKernelGGL((gemm_nt_kernel<T, false, false>), grid, block, 0, st, p);
-	else if (mode == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, true, true>), grid, block, 0, st, p);
-	else hipLaunchKernelGGL((gemm_nt_kernel<T, true, false>), grid, block, 0, st, p);
+#define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
+	if (mode == 1) { if (aligned) STPY_LAUNCH(false, true, 0); else STPY_LAUNCH(true, true, 0); }
+	else if (mode == 0) { if (aligned) STPY_LAUNCH(false, false, 0); else STPY_LAUNCH(true, false, 0); }
+	else if (mode == 3) { if (aligned) STPY_LAUNCH(false, false, 3); else STPY_LAUNCH(true, false, 3); }
+	else if (mode == 4) { if (aligned) STPY_LAUNCH(false, false, 4); else STPY_LAUNCH(true, false, 4); }
+	else if (mode == 2) {
+		if constexpr (sizeof(T) == 4) { if (aligned) STPY_LAUNCH(false, false, 2); else STPY_LAUNCH(true, false, 2); }
+	}
+	else { set_error("gemm_nt: unknown mode %d", mode); return -11; }
+#undef STPY_LAUNCH
 	return check_launch("gemm_nt");
 }
 

@@ -199,7 +199,7 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 		else hipLaunchKernelGGL((prep_points_kernel<T>), dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, b, q, ldb, d, dpad, cols, inv_ls, bs, nb);
 		int rc = check_launch("gram prep");
 		if (rc) return rc;
-		GramEpilogue<T> epi{kind, combine, (T)kappa, (T)(kind == STPY_K_LINEAR ? offset : 0.0), (T)diag_add, na, nb};
+		GramEpilogue<T> epi{kind, combine, (T)kappa, (T)(kind == STPY_K_LINEAR ? offset : 0.0), (T)diag_add, na, nb, nullptr, T(1)};
 		return gemm_nt<T>(q, n, dpad, bs, dpad, as, dpad, out, ldo, (T*)nullptr, 0, 3, lower_only, st, nullptr, nullptr, &epi);
 	}
 	if (n > INT32_MAX || q > INT32_MAX) { set_error("gram: dimension exceeds int32"); return -4; }
@@ -216,6 +216,26 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 	if (direct) hipLaunchKernelGGL((gram_kernel<T, true>), grid, dim3(G_THREADS), 0, st, p);
 	else hipLaunchKernelGGL((gram_kernel<T, false>), grid, dim3(G_THREADS), 0, st, p);
 	return check_launch("gram");
+}
+
+// H = (weight * Kinv - alpha alpha^T) o F  in place over the symmetric Kinv (n x n), F the derivative
+// factor of the kernel family (see gemm.hip, mode 4).  Same workspace layout as gram().
+template <typename T>
+int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, double kappa, double weight,
+               const T* alpha, T* H, int64_t ldh, void* work, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	if (kind < STPY_K_SE || kind > STPY_K_MATERN52) { set_error("lml_weight: kernel kind %d has no lengthscale gradient", kind); return -1; }
+	const int dpad = (d + 15) / 16 * 16;
+	char* w = (char*)work;
+	T* as = (T*)w; w += align16(n * (int64_t)dpad * sizeof(T));
+	w += align16(n * (int64_t)dpad * sizeof(T));
+	T* na = (T*)w;
+	hipLaunchKernelGGL((prep_points_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, ldx, d, dpad, cols, inv_ls, as, na);
+	int rc = check_launch("lml_weight prep");
+	if (rc) return rc;
+	GramEpilogue<T> epi{kind, 0, (T)kappa, T(0), T(0), na, na, alpha, (T)weight};
+	return gemm_nt<T>(n, n, dpad, as, dpad, as, dpad, H, ldh, (T*)nullptr, 0, 4, 0, st, nullptr, nullptr, &epi);
 }
 
 // k(x_i, x_i): stationary kernels give kappa * phi(0); LINEAR gives kappa ||x_i[cols] * inv_ls||^2 + offset
@@ -250,6 +270,7 @@ int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t
 }
 
 #define INST(T) \
+	template int lml_weight<T>(int, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, const T*, T*, int64_t, void*, hipStream_t); \
 	template int gram<T>(int, const T*, int64_t, int64_t, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, double, int, int, T*, int64_t, void*, hipStream_t); \
 	template int gram_diag<T>(int, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, int, T*, hipStream_t);
 INST(double)

@@ -9,8 +9,11 @@ namespace stpy {
 // B <- B L^-T,  B: m x n (rows = right-hand sides).  Same two-level blocking as potrf:
 // left-looking over 128-column blocks inside an nb-wide panel, right-looking between panels.
 // ------------------------------------------------------------------------------------------
+// upper_rhs: B is upper triangular on entry (the identity, for the inverse factor) and stays so: rows
+// below column block c are zero in that block, so every product is restricted to the rows above --
+// n^3/3 flops instead of n^3.
 template <typename T>
-int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st)
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs)
 {
 	if (nb <= 0) nb = TRSM_DEFAULT_NB;
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
@@ -20,26 +23,55 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 		for (int64_t c = k; c < k + kb; c += IB) {
 			const int64_t cb = (n - c < IB) ? (n - c) : IB;
 			const int64_t jj = c - k;
+			const int64_t mc = upper_rhs ? ((c + cb < m) ? c + cb : m) : m;       // rows that can be non-zero in this block column
 			if (jj > 0) {   // B[:, c:c+cb] -= B[:, k:c] L[c:c+cb, k:c]^T
-				ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)m * (double)cb * (double)jj, st);
-				rc = gemm_nt<T>(m, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
+				ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mc * (double)cb * (double)jj, st);
+				rc = gemm_nt<T>(mc, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
 				if (rc) return rc;
 			}
 			// B[:, c:c+cb] <- B[:, c:c+cb] inverse(L_cc)^T   (one column tile => safe in place)
 			{
-				ProfScope ps(TAG_TRSM_GEMM, (double)m * (double)cb * (double)cb, st);
-				rc = gemm_nt<T>(m, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
+				ProfScope ps(TAG_TRSM_GEMM, (double)mc * (double)cb * (double)cb, st);
+				rc = gemm_nt<T>(mc, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
 			}
 			if (rc) return rc;
 		}
 		if (k + kb < n) {   // B[:, k+kb:] -= B[:, k:k+kb] L[k+kb:, k:k+kb]^T
 			const int64_t r = k + kb;
-			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)m * (double)(n - r) * (double)kb, st);
-			rc = gemm_nt<T>(m, n - r, kb, B + k, ldb, L + r * ldl + k, ldl, B + r, ldb, (T*)nullptr, 0, 1, 0, st);
+			const int64_t mr = upper_rhs ? ((r < m) ? r : m) : m;                 // X[:, k:k+kb] is zero below row k+kb
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)(n - r) * (double)kb, st);
+			rc = gemm_nt<T>(mr, n - r, kb, B + k, ldb, L + r * ldl + k, ldl, B + r, ldb, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
 	}
 	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// K^-1 = L^-T L^-1 (lower triangle) from the factor: work <- I, work <- work L^-T (= L^-T, upper
+// triangular, rows restricted as above), Kinv <- work work^T on the lower tiles with the K range of
+// every tile row starting at its own first row.  2 n^3 / 3 flops, all on the MFMA GEMM.
+// (The evidence gradient needs tr(K^-1 dK/dtheta): SURVEY.md section 8f rank 1.)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void set_identity_kernel(T* __restrict__ A, int64_t lda, int64_t n)
+{
+	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= n * n) return;
+	const int64_t i = idx / n, j = idx - i * n;
+	A[i * lda + j] = (i == j) ? T(1) : T(0);
+}
+
+template <typename T>
+int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st)
+{
+	if (n <= 0) return 0;
+	hipLaunchKernelGGL((set_identity_kernel<T>), dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, work, n, n);
+	int rc = check_launch("potri identity");
+	if (rc) return rc;
+	rc = trsm_right_lt<T>(n, n, L, ldl, winv, work, n, 0, st, true);
+	if (rc) return rc;
+	return gemm_nt<T>(n, n, n, work, n, work, n, Kinv, ldk, (T*)nullptr, 0, 0, 2, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -260,7 +292,8 @@ int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st)
 }
 
 #define INST(T) \
-	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t); \
+	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t, bool); \
+	template int potri_lower<T>(int64_t, const T*, int64_t, const T*, T*, int64_t, T*, hipStream_t); \
 	template int trsv<T>(int64_t, const T*, int64_t, const T*, T*, T*, int, hipStream_t); \
 	template int predict<T>(int64_t, int64_t, const T*, int64_t, const T*, const T*, T*, T*, int, hipStream_t); \
 	template int logdet_quad<T>(int64_t, const T*, int64_t, const T*, T*, hipStream_t); \

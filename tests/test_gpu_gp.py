@@ -286,6 +286,83 @@ def test_sample_matches_seeded_reference_formula(S):
 	assert tuple(val.shape) == (2,)
 
 
+def _torch_lml(x, y, s, w, kind, ls, kappa):
+	"""the reference formula (gauss_procc.py:631-638) in torch CPU autograd, for gradient parity"""
+	xs = x / ls
+	if kind == "se":
+		sq = (xs ** 2).sum(1, keepdim=True) + (xs ** 2).sum(1, keepdim=True).T - 2 * xs @ xs.T
+		K = kappa * torch.exp(-0.5 * sq)
+	else:
+		diff = xs.unsqueeze(1) - xs.unsqueeze(0)
+		r = torch.sqrt((diff ** 2).sum(-1) + 1e-300)
+		if kind == "m12":
+			K = kappa * torch.exp(-r)
+		elif kind == "m32":
+			a = r * np.sqrt(3.0)
+			K = kappa * (1 + a) * torch.exp(-a)
+		else:
+			a = r * np.sqrt(5.0)
+			K = kappa * (1 + a + a ** 2 / 3.0) * torch.exp(-a)
+	K = K + torch.eye(x.shape[0], dtype=torch.float64) * s * s
+	return 0.5 * (y.T @ torch.linalg.solve(K, y)) + 0.5 * w * torch.slogdet(K)[1]
+
+
+@pytest.mark.parametrize("name,kind,nu", [("squared_exponential", "se", None), ("matern", "m32", 1.5), ("matern", "m52", 2.5), ("matern", "m12", 0.5)])
+def test_log_marginal_gradient_isotropic(S, name, kind, nu):
+	"""d log_marginal / d gamma through autograd, vs torch CPU autograd of the reference formula."""
+	rng = np.random.RandomState(5)
+	n, d = 300, 3
+	x = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)))
+	y = torch.sin(3 * x[:, :1]) + 0.1 * torch.from_numpy(rng.normal(size=(n, 1)))
+	kw = dict(nu=nu) if nu else {}
+	GP = S.GaussianProcess(gamma=0.9, s=0.2, kappa=1.3, kernel_name=name, d=d, **kw)
+	GP.load_data((x, y))
+	for w in (1.0, 0.5):
+		g = torch.tensor([0.7], dtype=torch.float64, requires_grad=True)
+		f = GP.log_marginal(GP.kernel_object, {'0': {'gamma': g}}, w)
+		assert tuple(f.shape) == (1, 1)
+		f.backward()
+		gr = torch.tensor([0.7], dtype=torch.float64, requires_grad=True)
+		fr = _torch_lml(x, y, 0.2, w, kind, gr, 1.3)
+		fr.backward()
+		assert abs(float(f) - float(fr)) / abs(float(fr)) < 1e-9
+		assert abs(float(g.grad) - float(gr.grad)) / abs(float(gr.grad)) < 1e-7
+
+
+def test_log_marginal_gradient_ard_and_noise(S):
+	rng = np.random.RandomState(6)
+	n, d = 257, 4
+	x = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)))
+	y = torch.cos(x @ torch.tensor([[1.0], [0.5], [2.0], [0.1]], dtype=torch.float64)) + 0.05 * torch.from_numpy(rng.normal(size=(n, 1)))
+	ag0 = torch.tensor([0.5, 1.0, 2.0, 4.0], dtype=torch.float64)
+	for name, kind, nu in (("ard", "se", None), ("ard_matern", "m52", 2.5)):
+		kw = dict(nu=nu) if nu else {}
+		GP = S.GaussianProcess(s=0.2, kernel=S.KernelFunction(kernel_name=name, ard_gamma=ag0.clone(), kappa=1.2, d=d, **kw))
+		GP.load_data((x, y))
+		ag = ag0.clone().requires_grad_(True)
+		f = GP.log_marginal(GP.kernel_object, {'0': {'ard_gamma': ag}}, 1.0)
+		f.backward()
+		agr = ag0.clone().requires_grad_(True)
+		fr = _torch_lml(x, y, 0.2, 1.0, kind, agr, 1.2)
+		fr.backward()
+		assert abs(float(f) - float(fr)) / abs(float(fr)) < 1e-9
+		assert rel_err(ag.grad.numpy(), agr.grad.numpy()) < 1e-7
+	# noise std through self.s (the "bandwidth+noise" mode, estimator.py:163-166) together with gamma
+	GP = S.GaussianProcess(gamma=0.8, s=0.3, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.load_data((x, y))
+	sig = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+	g = torch.tensor([0.8], dtype=torch.float64, requires_grad=True)
+	GP.s = sig
+	f = GP.log_marginal(GP.kernel_object, {'0': {'gamma': g}}, 1.0)
+	f.backward()
+	sr = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+	gr = torch.tensor([0.8], dtype=torch.float64, requires_grad=True)
+	fr = _torch_lml(x, y, sr, 1.0, "se", gr, 1.0)
+	fr.backward()
+	assert abs(float(g.grad) - float(gr.grad)) / abs(float(gr.grad)) < 1e-7
+	assert abs(float(sig.grad) - float(sr.grad)) / abs(float(sr.grad)) < 1e-7
+
+
 def test_not_positive_definite_raises(S):
 	x = torch.zeros((300, 2), dtype=torch.float64)        # 300 identical points, no noise -> singular
 	GP = S.GaussianProcess(gamma=1.0, s=0.0, kappa=1.0, kernel_name="squared_exponential", d=2)

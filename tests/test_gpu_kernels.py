@@ -279,6 +279,26 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	assert abs(o[1] - zref @ zref) < 1e-10 * abs(zref @ zref)
 
 
+@pytest.mark.parametrize("n,nb", [(128, 0), (300, 128), (1024, 256), (1500, 0)])
+def test_potri(L, n, nb):
+	"""K^-1 from the factor: upper-triangular-aware trsm + K-skipping SYRK"""
+	rng = np.random.RandomState(n + 1)
+	K = spd(rng, n)
+	Ld, winv, info = run_potrf(L, K, nb)
+	assert info == 0
+	lib = L.load()
+	Kinv = torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda:0")
+	work = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_potri(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Kinv), n, L.ptr(work), L.stream_ptr()), "potri")
+	out = Kinv.cpu().numpy()
+	ref = np.linalg.inv(K)
+	il = np.tril_indices(n)
+	assert rel_err(out[il], ref[il]) < 1e-10
+	# the scratch buffer holds L^-T (upper triangular)
+	LinvT = np.linalg.inv(np.linalg.cholesky(K)).T
+	assert rel_err(np.triu(work.cpu().numpy()), LinvT) < 1e-10
+
+
 def test_predict_negative_variance_is_nan_unless_clamped(L):
 	"""gauss_procc.py:394-395: sqrt of an unclamped difference."""
 	lib = L.load()
