@@ -363,6 +363,34 @@ def test_log_marginal_gradient_ard_and_noise(S):
 	assert abs(float(sig.grad) - float(sr.grad)) / abs(float(sr.grad)) < 1e-7
 
 
+def test_optimize_params_bandwidth(S):
+	"""the caller of the hot path (estimator.py:141-256): L-BFGS on the device evidence reaches the optimum that
+	the same optimiser reaches on the torch-CPU restatement of the reference objective"""
+	import scipy.optimize
+	rng = np.random.RandomState(8)
+	n, d = 200, 2
+	x = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)))
+	y = torch.sin(3 * x[:, :1]) * torch.cos(2 * x[:, 1:2]) + 0.1 * torch.from_numpy(rng.normal(size=(n, 1)))
+	GP = S.GaussianProcess(gamma=0.3, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(x, y)
+	f0 = lml(GP)
+	GP.optimize_params(type="bandwidth", restarts=2, optimizer="pytorch-minimize", init_func=lambda dim: np.full(dim, 0.3), maxiter=200)
+	g_opt = float(GP.kernel_object.params_dict['0']['gamma'].reshape(-1)[0])
+	f1 = lml(GP)
+	assert f1 < f0 and GP.fitted
+
+	def fun(v):
+		t = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+		f = _torch_lml(x, y, 0.1, 1.0, "se", t, 1.0)
+		f.backward()
+		return float(f), t.grad.numpy()
+	ref = scipy.optimize.minimize(fun, np.array([0.3]), jac=True, method='L-BFGS-B', options={'gtol': 1e-4, 'ftol': 1e-12})
+	assert abs(abs(g_opt) - abs(ref.x[0])) / abs(ref.x[0]) < 1e-4
+	assert abs(f1 - ref.fun) / abs(ref.fun) < 1e-8
+	mu, std = GP.mean_std(x[:10])
+	assert mu.shape == (10, 1) and not bool(torch.isnan(std).any())
+
+
 def test_not_positive_definite_raises(S):
 	x = torch.zeros((300, 2), dtype=torch.float64)        # 300 identical points, no noise -> singular
 	GP = S.GaussianProcess(gamma=1.0, s=0.0, kappa=1.0, kernel_name="squared_exponential", d=2)
