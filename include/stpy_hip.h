@@ -153,10 +153,12 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
  *                                  scale * sin(<W_j, x_i>)  for j >= m/2
  *   bias != NULL: out[i*ldo + j] = scale * cos(<W_j, x_i> + bias[j])
  * x: n x ldx (d columns used), W: m x ldw, out: n x m;  scale = sqrt(2/m) * sqrt(kappa).
+ * transposed != 0 writes Phi^T instead (out: m x n, out[j*ldo + i]) -- the "row x K" operand the
+ * feature-space normal equations Phi^T Phi need (kernelized_features.py:236-240).
  */
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
                    const void* W, int64_t ldw, int64_t m, const void* bias, double scale,
-                   void* out, int64_t ldo, void* stream);
+                   void* out, int64_t ldo, int transposed, void* stream);
 
 /*
  * Launch profiler (bench.py's live roofline numbers).  While enabled, HIP events are recorded on

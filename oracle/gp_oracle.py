@@ -245,6 +245,29 @@ def rff_sample_W(gamma, m, d, rng_state=None):
 
 
 # --------------------------------------------------------------------------------------------
+# Primal ridge regression on a finite feature map  (stpy/continuous_processes/kernelized_features.py)
+# --------------------------------------------------------------------------------------------
+
+def kernelized_features_fit(Q, y, s, lam):
+	"""kernelized_features.py:236-240 + :252-253 (primal): V = Q^T Q + s^2 lam I, invV = pinv(V),
+	theta = invV Q^T y, Z = s^2 invV."""
+	Q = np.asarray(Q, dtype=np.float64)
+	m = Q.shape[1]
+	V = Q.T @ Q + s ** 2 * lam * np.eye(m)
+	invV = np.linalg.pinv(V)
+	theta = invV @ Q.T @ np.asarray(y, dtype=np.float64).reshape(-1, 1)
+	return V, invV, theta
+
+
+def kernelized_features_mean_std(Qtest, invV, theta, s):
+	"""kernelized_features.py:269-288: mean = Phi* theta, std = sqrt(s^2 diag(Phi* invV Phi*^T))."""
+	Qtest = np.asarray(Qtest, dtype=np.float64)
+	mean = Qtest @ theta
+	diag = s ** 2 * np.einsum('ij,jk,ik->i', Qtest, invV, Qtest).reshape(-1, 1)
+	return mean, np.sqrt(diag)
+
+
+# --------------------------------------------------------------------------------------------
 # synthetic workloads shared by tests and bench  (SURVEY.md section 8d)
 # --------------------------------------------------------------------------------------------
 

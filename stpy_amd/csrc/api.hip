@@ -207,14 +207,14 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
 }
 
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, const void* W, int64_t ldw, int64_t m,
-                   const void* bias, double scale, void* out, int64_t ldo, void* stream)
+                   const void* bias, double scale, void* out, int64_t ldo, int transposed, void* stream)
 {
 	if (!x || !W || !out) { set_error("stpy_rff_embed: null pointer"); return -2; }
-	if (d <= 0 || ldx < d || ldw < d || ldo < m) { set_error("stpy_rff_embed: bad dimensions"); return -5; }
+	if (d <= 0 || ldx < d || ldw < d || ldo < (transposed ? n : m)) { set_error("stpy_rff_embed: bad dimensions"); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, scale, (double*)out, ldo, st),
-	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, scale, (float*)out, ldo, st));
+	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, scale, (double*)out, ldo, transposed, st),
+	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, scale, (float*)out, ldo, transposed, st));
 }
 
 /* experiment knobs (benchmarks only): key 0 = gemm first-round stagger on/off */

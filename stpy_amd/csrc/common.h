@@ -50,7 +50,7 @@ template <> struct Mfma<float> {
 
 // ---- internal launchers (all enqueue on `st`, return 0 or a negative error code) ----
 struct BlockCyclic { int nb_dist, pr, pc, myr, myc, i0, j0; };
-template <typename T> struct RffEpilogue { int half; T scale; const T* bias; };
+template <typename T> struct RffEpilogue { int half; T scale; const T* bias; int by_row; };
 template <typename T> struct GramEpilogue { int kind, combine; T kappa, offset, diag_add; const T* na; const T* nb; const T* alpha; T weight; };
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
@@ -85,6 +85,6 @@ int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t
               double kappa, double offset, int combine, T* out, hipStream_t st);
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
-              const T* bias, double scale, T* out, int64_t ldo, hipStream_t st);
+              const T* bias, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
 
 }  // namespace stpy

@@ -45,6 +45,7 @@ struct GemmArgs {
 	int epi_half;            // mode 2: columns < epi_half take cos, the rest sin (all cos when epi_bias != null)
 	T epi_scale;             // mode 2: output scale sqrt(2/m) sqrt(kappa)
 	const T* epi_bias;       // mode 2: optional phase per column
+	int epi_by_row;          // mode 2: features run along the ROWS of C (transposed embedding Phi^T)
 	// mode 3: Gram epilogue  C[j][i] (op)= kappa * phi(nb[j] + na[i] - 2 acc) (+ offset) + diag_add [i == j]
 	const T* g_na; const T* g_nb;
 	T g_kappa, g_offset, g_diag;
@@ -342,21 +343,34 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// indexes `acc` at run time and moves ALL accumulators to scratch -- for every use of the
 	// kernel, 5x slower (guide rule 20).  fp64 embeds take the unfused route in rff.hip instead.
 	if constexpr (EPI == 2) {
-		T bias[4];
-		bool use_cos[4];
+		if (!p.epi_by_row) {
+			T bias[4];
+			bool use_cos[4];
 #pragma unroll
-		for (int tn = 0; tn < 4; ++tn) {
-			const int col = col0 + wn * 64 + r16 + tn * 16;
-			bias[tn] = p.epi_bias ? p.epi_bias[GUARD ? min(col, p.n - 1) : col] : T(0);
-			use_cos[tn] = p.epi_bias != nullptr || col < p.epi_half;
+			for (int tn = 0; tn < 4; ++tn) {
+				const int col = col0 + wn * 64 + r16 + tn * 16;
+				bias[tn] = p.epi_bias ? p.epi_bias[GUARD ? min(col, p.n - 1) : col] : T(0);
+				use_cos[tn] = p.epi_bias != nullptr || col < p.epi_half;
+			}
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+						acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + bias[tn], use_cos[tn], p.epi_scale);
+		} else {
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int row = row0 + wm * 64 + tm * 16 + MM::crow(lane, i);
+					const T b = p.epi_bias ? p.epi_bias[GUARD ? min(row, p.m - 1) : row] : T(0);
+					const bool uc = p.epi_bias != nullptr || row < p.epi_half;
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + b, uc, p.epi_scale);
+				}
 		}
-#pragma unroll
-		for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-			for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-				for (int i = 0; i < 4; ++i)
-					acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + bias[tn], use_cos[tn], p.epi_scale);
 	}
 
 	// ---- fused Gram epilogue (mode 3): norms of the (pre-scaled) points come from the workspace.
@@ -521,10 +535,10 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.tiles_m = (int)((m + BM - 1) / BM);
 	p.tiles_n = (int)((n + BN - 1) / BN);
 	p.mode = mode;
-	p.epi_half = 0; p.epi_scale = T(1); p.epi_bias = nullptr;
+	p.epi_half = 0; p.epi_scale = T(1); p.epi_bias = nullptr; p.epi_by_row = 0;
 	if (mode == 2) {
 		if (!rff || sizeof(T) != 4) { set_error("gemm_nt: mode 2 (fused RFF epilogue) is fp32 only and needs its parameters"); return -12; }
-		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias;
+		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias; p.epi_by_row = rff->by_row;
 	}
 	p.g_na = p.g_nb = nullptr; p.g_kappa = T(1); p.g_offset = p.g_diag = T(0); p.g_kind = 0; p.g_combine = 0;
 	p.g_alpha = nullptr; p.g_w = T(1); p.kskip = 0;

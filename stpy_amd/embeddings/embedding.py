@@ -75,21 +75,30 @@ class RFFEmbedding(Embedding):
 			self.b = torch.from_numpy(self.b)
 			self.bs = torch.from_numpy(self.bs)
 
+	def _embed_device(self, xd, transposed):
+		lib = _lib.load()
+		(times, d) = xd.shape
+		Wd = _lib.to_device(self.W, xd.dtype)
+		bd = _lib.to_device(self.b, xd.dtype) if self.biased == True else None
+		shape = (self.m, times) if transposed else (times, self.m)
+		out = torch.empty(shape, dtype=xd.dtype, device=xd.device)
+		scale = float(np.sqrt(2. / float(self.m)) * np.sqrt(self.kappa))
+		rc = lib.stpy_rff_embed(_lib.dtype_code(xd.dtype), _lib.ptr(xd), times, xd.stride(0), d, _lib.ptr(Wd), Wd.stride(0),
+								self.m, _lib.ptr(bd), scale, _lib.ptr(out), out.stride(0), 1 if transposed else 0, _lib.stream_ptr())
+		_lib.check(rc, "stpy_rff_embed")
+		return out
+
 	def embed(self, x):
 		"""
 		embedding.py:225-241.  x: (n, d_x) -> (n, m); uses W[:, 0:d_x].  With ``biased=True`` the
 		reference transposes twice (:232 and :241) and returns (m, n); that orientation is kept.
 		"""
-		lib = _lib.load()
-		xd = _lib.to_device(x)
-		(times, d) = xd.shape
-		Wd = _lib.to_device(self.W, xd.dtype)
-		bd = _lib.to_device(self.b, xd.dtype) if self.biased == True else None
-		out = torch.empty((times, self.m), dtype=xd.dtype, device=xd.device)
-		scale = float(np.sqrt(2. / float(self.m)) * np.sqrt(self.kappa))
-		rc = lib.stpy_rff_embed(_lib.dtype_code(xd.dtype), _lib.ptr(xd), times, xd.stride(0), d, _lib.ptr(Wd), Wd.stride(0),
-								self.m, _lib.ptr(bd), scale, _lib.ptr(out), out.stride(0), _lib.stream_ptr())
-		_lib.check(rc, "stpy_rff_embed")
+		out = self._embed_device(_lib.to_device(x), False)
 		if self.biased == True:
 			out = torch.t(out)
 		return _lib.like_input(out, x)
+
+	def embed_t(self, x):
+		"""Phi^T, (m, n): the operand layout of the feature-space solves (no reference counterpart; used by
+		KernelizedFeatures so that Phi^T Phi is an NT contraction)."""
+		return _lib.like_input(self._embed_device(_lib.to_device(x), True), x)

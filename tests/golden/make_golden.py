@@ -56,6 +56,9 @@ def N(t):
 
 def save(name, **arrays):
 	path = os.path.join(HERE, name + ".npz")
+	if os.path.exists(path) and "--force" not in sys.argv:
+		print("%-28s kept (exists; --force regenerates)" % (name + ".npz"))
+		return
 	np.savez_compressed(path, **arrays)
 	print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
 
@@ -289,6 +292,23 @@ def main():
 	mu2, std2 = GP2.mean_std(T(xtest))
 	save("G11_lu_branch", x=x, y=y, xtest=xtest, gamma=np.array(1.0), s=np.array(0.1), mu_lu=N(mu), std_lu=N(std),
 		 mu=N(mu2), std=N(std2))
+
+	# ---------------------------------------------------------------- G12: KernelizedFeatures (primal ridge on RFF features)
+	from stpy.continuous_processes.kernelized_features import KernelizedFeatures
+	rng12 = np.random.RandomState(121)
+	m, d, Ntr, M = 64, 3, 300, 50
+	W = rng12.normal(size=(m, d)) / 0.8
+	x = rng12.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(2 * x[:, :1]) + x[:, 1:2] * x[:, 2:3] + 0.1 * rng12.normal(size=(Ntr, 1))
+	xtest = rng12.uniform(-1, 1, size=(M, d))
+	emb = RFFEmbedding(gamma=0.8, m=m, d=d, kappa=1.5)
+	emb.W = T(W)
+	KF = KernelizedFeatures(embedding=emb, m=m, s=0.2, lam=1.3, d=d)
+	KF.fit_gp(T(x), T(y))
+	mu, std = KF.mean_std(T(xtest))
+	theta, Z = KF.theta_mean(var=True)
+	save("G12_kernelized_features", W=W, x=x, y=y, xtest=xtest, gamma=np.array(0.8), kappa=np.array(1.5), s=np.array(0.2), lam=np.array(1.3),
+		 mu=N(mu), std=N(std), theta=N(theta), Z_head=N(Z[:8, :8]), V_head=N(KF.V[:8, :8]), kernel_head=N(KF.kernel(T(x[:5]), T(x[:7]))))
 
 	# ---------------------------------------------------------------- H1: helpers
 	save("H1_helpers", interval_5_2=helper.interval(5, 2), interval_4_1_half=helper.interval(4, 1, L_infinity_ball=0.5),

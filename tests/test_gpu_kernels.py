@@ -332,10 +332,27 @@ def test_rff(L, n, d, m):
 	out = torch.empty((n, m), dtype=torch.float64, device="cuda:0")
 	scale = np.sqrt(2.0 / m) * np.sqrt(2.5)
 	xd, Wd, bd = dev(x), dev(W), dev(b)          # keep the device buffers alive across the launches
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), m, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5)) < 1e-14
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), m, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5, b=b).T) < 1e-14
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-14), (torch.float32, 2e-5)])
+def test_rff_transposed(L, dtype, tol):
+	rng = np.random.RandomState(21)
+	n, d, m = 300, 7, 130
+	x, W, b = rng.uniform(0, 1, size=(n, d)), rng.normal(size=(m, d)) / 0.7, 2 * np.pi * rng.uniform(size=m)
+	lib = L.load()
+	xd, Wd, bd = dev(x, dtype), dev(W, dtype), dev(b, dtype)
+	out = torch.empty((m, n), dtype=dtype, device="cuda:0")
+	scale = np.sqrt(2.0 / m)
+	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
+	ref = O.rff_embed(x, W, m).T
+	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
+	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
+	ref = O.rff_embed(x, W, m, b=b)          # the reference's biased orientation is already (m, n)
+	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
 
 
 def test_rff_f32(L):
@@ -346,7 +363,7 @@ def test_rff_f32(L):
 	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
 	xd, Wd = dev(x, torch.float32), dev(W, torch.float32)
 	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None,
-							   float(np.sqrt(2.0 / m)), L.ptr(out), m, L.stream_ptr()), "rff")
+							   float(np.sqrt(2.0 / m)), L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x.astype(np.float64), W.astype(np.float64), m)
 	assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max() * 10
 

@@ -185,6 +185,23 @@ def test_G10_rff():
 	assert rel_err(O.rff_sample_W(0.7, 8, 3, rng_state=0), g["W_seed0_biased"]) < 1e-15
 
 
+def test_G12_kernelized_features():
+	g = golden("G12_kernelized_features")
+	m = g["W"].shape[0]
+	s, lam = float(g["s"]), float(g["lam"])
+	Q = O.rff_embed(g["x"], g["W"], m, kappa=float(g["kappa"]))
+	V, invV, theta = O.kernelized_features_fit(Q, g["y"], s, lam)
+	assert rel_err(V[:8, :8], g["V_head"]) < 1e-13
+	assert rel_err(theta, g["theta"]) < 1e-9
+	assert rel_err((s ** 2 * invV)[:8, :8], g["Z_head"]) < 1e-9
+	mu, std = O.kernelized_features_mean_std(O.rff_embed(g["xtest"], g["W"], m, kappa=float(g["kappa"])), invV, theta, s)
+	assert rel_err(mu, g["mu"]) < 1e-9 and rel_err(std, g["std"]) < 1e-9
+	Qa, Qb = O.rff_embed(g["x"][:5], g["W"], m, kappa=float(g["kappa"])), O.rff_embed(g["x"][:7], g["W"], m, kappa=float(g["kappa"]))
+	# reference quirk: KernelizedFeatures.kernel goes through KernelFunction(kernel_name="linear") built with the
+	# default d=1, i.e. group=[0] (kernelized_features.py:49) -> only the FIRST feature column enters
+	assert rel_err(O.linear(Qa, Qb, group=[0]), g["kernel_head"]) < 1e-13 and g["kernel_head"].shape == (7, 5)
+
+
 def test_H1_helpers():
 	g = golden("H1_helpers")
 	assert np.array_equal(O.interval(5, 2), g["interval_5_2"])

@@ -75,6 +75,29 @@ def c5():
 	print("    max abs err vs fp64 on a 256-row slice: %.2e (|z| <= %.2e)" % (float((zs - ref).abs().max()), math.sqrt(2.0 / m)), flush=True)
 
 
+def grad():
+	"""one evidence + gradient evaluation (the unit of work of optimize_params), SE, d = 16"""
+	for n in (16384, 32768):
+		d = 16
+		x, y, _ = synth(n, d, 16, dev)
+		gp = GaussianProcess(gamma=math.sqrt(d), s=0.1, kernel_name="squared_exponential", d=d)
+		gp.load_data((x, y))
+		def step():
+			g = torch.tensor([math.sqrt(d)], dtype=torch.float64, requires_grad=True)
+			f = gp.log_marginal(gp.kernel_object, {'0': {'gamma': g}}, 1.0)
+			f.backward()
+			return float(f.detach()), float(g.grad)
+		def fwd():
+			return float(gp.log_marginal(gp.kernel_object, {'0': {'gamma': torch.tensor(math.sqrt(d)).double()}}, 1.0))
+		tf, _ = timed(fwd)
+		t, (f, g) = timed(step)
+		F = n ** 3 / 3.0
+		print("grad N=%d d=16 SE: value only %.4f s (%.1f TF/s of n^3/3); value+gradient %.4f s = %.2fx  (3 n^3/3 flop -> %.1f TF/s)  f=%.6f df/dgamma=%.6f"
+			  % (n, tf, F / tf / 1e12, t, t / tf, 3 * F / t / 1e12, f, g), flush=True)
+		del gp
+		torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
 	for name in (sys.argv[1:] or ["c2", "c3", "c5"]):
 		globals()[name]()
