@@ -394,11 +394,12 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 				for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
-					for (int i = 0; i < 4; ++i)
+					for (int i = 0; i < 4; ++i) {
 						acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)]) + p.g_offset;
-					// four independent exp chains at a time are enough to cover the FMA latency; letting
-					// the scheduler interleave all 64 costs >250 spilled VGPRs
-					__builtin_amdgcn_sched_barrier(0);
+						// two independent exp chains at a time cover the FMA latency (two waves per SIMD fill
+						// the rest); letting the scheduler interleave all 64 costs >250 spilled VGPRs
+						if (i & 1) __builtin_amdgcn_sched_barrier(0);
+					}
 				}
 		};
 		switch (p.g_kind) {
@@ -407,10 +408,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		case STPY_K_MATERN52: apply(std::integral_constant<int, STPY_K_MATERN52>{}); break;
 		default: apply(std::integral_constant<int, STPY_K_LINEAR>{}); break;
 		}
-		if (p.g_combine != STPY_OUT_SET) {
+		if (p.g_combine != STPY_OUT_SET) {         // kernel algebra: out (+|*)= k, the old tile read 16 values at a time
 			const bool add = p.g_combine == STPY_OUT_ADD;
 #pragma unroll
-			for (int tm = 0; tm < 4; ++tm)
+			for (int tm = 0; tm < 4; ++tm) {
+				T old[4][4];
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
 					const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
@@ -418,10 +420,16 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 					for (int tn = 0; tn < 4; ++tn) {
 						const int lc = wn * 64 + r16 + tn * 16;
-						const T old = ctile[(unsigned)lrc * ldc32 + (unsigned)(GUARD ? min(lc, p.n - 1 - col0) : lc)];
-						acc[tm][tn][i] = add ? old + acc[tm][tn][i] : old * acc[tm][tn][i];
+						old[tn][i] = ctile[(unsigned)lrc * ldc32 + (unsigned)(GUARD ? min(lc, p.n - 1 - col0) : lc)];
 					}
 				}
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn)
+						acc[tm][tn][i] = add ? old[tn][i] + acc[tm][tn][i] : old[tn][i] * acc[tm][tn][i];
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 		if (p.g_diag != T(0) && row0 == col0) {         // tiles are 128-aligned: only diagonal tiles hold i == j
 #pragma unroll

@@ -62,13 +62,13 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 		vspill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
 		vgprs = int(re.search(r"\bVGPRs: (\d+)", b).group(1))
 		if "gemm_nt_kernel" in name:
-			# the accumulate (SUB) instantiations -- the Cholesky / solve work-horses -- must be spill free
-			# (2 VGPRs outside the K loop tolerated); the plain instantiations carry the fused Gram
-			# epilogue, whose exp chains spill a few values AFTER the K loop
-			if "Lb1EEEv" in name:
-				assert vspill <= 2 and scratch <= 16, (name, scratch, vspill)
+			# plain / accumulate instantiations (EPI = 0: the Cholesky and solve work-horses) must be spill
+			# free; the fused-epilogue instantiations (EPI = 2, 3, 4) may spill epilogue temporaries AFTER
+			# the K loop, but not so much that the accumulators themselves are in scratch (>= 512 B)
+			if "ELi0EEEv" in name:
+				assert vspill == 0 and scratch == 0, (name, scratch, vspill)
 			else:
-				assert vspill <= 100 and scratch <= 160, (name, scratch, vspill)
+				assert scratch < 400, (name, scratch, vspill)
 			assert vgprs <= 256
 		else:
 			assert vspill == 0 and scratch == 0, (name, scratch, vspill)
