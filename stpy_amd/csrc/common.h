@@ -17,6 +17,16 @@ extern int g_potf2_scalar;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// ---- look-ahead side stream (highest priority) + events shared by potrf and the block solves; one set per
+// ---- process, created on first use
+struct LookAhead {
+	hipStream_t side = nullptr;
+	hipEvent_t col_ready = nullptr, panel_done = nullptr, trail_done = nullptr;
+	int device = -1;
+};
+int lookahead_init();
+LookAhead* lookahead_state();
+
 // ---- optional launch profiler (stpy_profile_*): HIP events recorded on the launch stream around
 // ---- every tagged kernel, so bench.py can report the dominant kernel's live average duration.
 enum { TAG_SYRK = 0, TAG_PANEL_GEMM = 1, TAG_TRSM_GEMM = 2, TAG_POTF2 = 3, TAG_GEMM_API = 4, TAG_COUNT = 5 };

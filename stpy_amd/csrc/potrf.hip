@@ -357,14 +357,11 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 // Side stream + events for the look-ahead (one set per process, created on first use; the side
 // stream has the highest priority so the small panel kernels are dispatched ahead of the queued
 // trailing-update workgroups as CU slots free up).
-struct LookAhead {
-	hipStream_t side = nullptr;
-	hipEvent_t col_ready = nullptr, panel_done = nullptr, trail_done = nullptr;
-	int device = -1;
-};
 static LookAhead g_la;
 
-static int lookahead_init()
+LookAhead* lookahead_state() { return &g_la; }
+
+int lookahead_init()
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { set_error("potrf: hipGetDevice failed"); return -1001; }

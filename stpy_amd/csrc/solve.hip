@@ -12,37 +12,66 @@ namespace stpy {
 // upper_rhs: B is upper triangular on entry (the identity, for the inverse factor) and stays so: rows
 // below column block c are zero in that block, so every product is restricted to the rows above --
 // n^3/3 flops instead of n^3.
+// the 128-column blocks of one nb-wide panel, left-looking (small, latency-bound launches)
+template <typename T>
+static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs)
+{
+	int rc;
+	for (int64_t c = k; c < k + kb; c += IB) {
+		const int64_t cb = (n - c < IB) ? (n - c) : IB;
+		const int64_t jj = c - k;
+		const int64_t mc = upper_rhs ? ((c + cb < m) ? c + cb : m) : m;       // rows that can be non-zero in this block column
+		if (jj > 0) {   // B[:, c:c+cb] -= B[:, k:c] L[c:c+cb, k:c]^T
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mc * (double)cb * (double)jj, st);
+			rc = gemm_nt<T>(mc, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
+			if (rc) return rc;
+		}
+		// B[:, c:c+cb] <- B[:, c:c+cb] inverse(L_cc)^T   (one column tile => safe in place)
+		{
+			ProfScope ps(TAG_TRSM_GEMM, (double)mc * (double)cb * (double)cb, st);
+			rc = gemm_nt<T>(mc, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
+		}
+		if (rc) return rc;
+	}
+	return 0;
+}
+
+#define HIPCHK_S(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("trsm: %s failed: %s", #x, hipGetErrorString(e_)); return -1000 - (int)e_; } } while (0)
+
+// Right-looking between panels with one panel of look-ahead (same scheme as potrf): after panel k is
+// solved, the update of the NEXT panel's columns goes first, then the next panel's latency-bound
+// 128-blocks run on the side stream while the caller's stream updates the remaining columns.
 template <typename T>
 int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs)
 {
 	if (nb <= 0) nb = TRSM_DEFAULT_NB;
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
-	int rc;
-	for (int64_t k = 0; k < n; k += nb) {
-		const int64_t kb = (n - k < nb) ? (n - k) : nb;
-		for (int64_t c = k; c < k + kb; c += IB) {
-			const int64_t cb = (n - c < IB) ? (n - c) : IB;
-			const int64_t jj = c - k;
-			const int64_t mc = upper_rhs ? ((c + cb < m) ? c + cb : m) : m;       // rows that can be non-zero in this block column
-			if (jj > 0) {   // B[:, c:c+cb] -= B[:, k:c] L[c:c+cb, k:c]^T
-				ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mc * (double)cb * (double)jj, st);
-				rc = gemm_nt<T>(mc, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
-				if (rc) return rc;
-			}
-			// B[:, c:c+cb] <- B[:, c:c+cb] inverse(L_cc)^T   (one column tile => safe in place)
-			{
-				ProfScope ps(TAG_TRSM_GEMM, (double)mc * (double)cb * (double)cb, st);
-				rc = gemm_nt<T>(mc, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
-			}
+	int rc = lookahead_init();
+	if (rc) return rc;
+	LookAhead* la = lookahead_state();
+	rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs);
+	if (rc) return rc;
+	for (int64_t k = 0; k + nb < n; k += nb) {
+		const int64_t r = k + nb;
+		const int64_t nkb = (n - r < nb) ? (n - r) : nb;
+		const int64_t mr = upper_rhs ? ((r < m) ? r : m) : m;                 // X[:, k:k+nb] is zero below row k+nb
+		{   // next panel's columns: B[:, r:r+nkb] -= B[:, k:r] L[r:r+nkb, k:r]^T
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)nkb * (double)nb, st);
+			rc = gemm_nt<T>(mr, nkb, nb, B + k, ldb, L + r * ldl + k, ldl, B + r, ldb, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
-		if (k + kb < n) {   // B[:, k+kb:] -= B[:, k:k+kb] L[k+kb:, k:k+kb]^T
-			const int64_t r = k + kb;
-			const int64_t mr = upper_rhs ? ((r < m) ? r : m) : m;                 // X[:, k:k+kb] is zero below row k+kb
-			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)(n - r) * (double)kb, st);
-			rc = gemm_nt<T>(mr, n - r, kb, B + k, ldb, L + r * ldl + k, ldl, B + r, ldb, (T*)nullptr, 0, 1, 0, st);
+		HIPCHK_S(hipEventRecord(la->col_ready, st));
+		HIPCHK_S(hipStreamWaitEvent(la->side, la->col_ready, 0));
+		rc = solve_panel<T>(m, n, r, nkb, L, ldl, winv, B, ldb, la->side, upper_rhs);
+		if (rc) return rc;
+		HIPCHK_S(hipEventRecord(la->panel_done, la->side));
+		if (r + nkb < n) {  // the rest: B[:, r+nkb:] -= B[:, k:r] L[r+nkb:, k:r]^T
+			const int64_t r2 = r + nkb;
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)(n - r2) * (double)nb, st);
+			rc = gemm_nt<T>(mr, n - r2, nb, B + k, ldb, L + r2 * ldl + k, ldl, B + r2, ldb, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
+		HIPCHK_S(hipStreamWaitEvent(st, la->panel_done, 0));
 	}
 	return 0;
 }
