@@ -122,8 +122,22 @@ def small_k():
 			print("n=%d k=%4d mode=%d: %.3f ms  (%.2f us per round of 512 tiles)  C-bytes/time = %.2f TB/s" % (n, k, mode, t * 1e3, t * 1e6 / (32896 / 512.0), (2 if mode else 1) * n * n * 4 / t / 1e12), flush=True)
 
 
+def rect():
+	"""the shapes of the block solve: C (m x n) -= A (m x k) B^T, m = 4096"""
+	for m, n, k in ((4096, 65536, 512), (4096, 32768, 512), (4096, 65536, 1024), (8192, 32768, 512), (4096, 65536, 256)):
+		A = torch.randn(m, k, dtype=torch.float64, device=dev)
+		B = torch.randn(n, k, dtype=torch.float64, device=dev)
+		C = torch.randn(m, n, dtype=torch.float64, device=dev)
+		f = lambda: L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(A), k, L.ptr(B), k, L.ptr(C), n, 1, 0, L.stream_ptr()), "gemm")
+		t = timeit(f, reps=3, warm=1)[0]
+		print("rect m=%d n=%d k=%d: %.3f ms  %.1f TF" % (m, n, k, t * 1e3, 2.0 * m * n * k / t / 1e12), flush=True)
+		del A, B, C
+
+
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "rect":
+		rect()
 	if which == "smallk":
 		small_k()
 	if which == "abfit":
