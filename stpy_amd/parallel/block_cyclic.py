@@ -251,21 +251,29 @@ class DistributedGaussianProcess:
 					dblk.add_(torch.where(gdiag < n, torch.full_like(dblk, s2), torch.ones_like(dblk)))
 		self._Aloc = Aloc
 		self._winv = {}
-		bad = torch.zeros((1,), dtype=torch.int32, device=xd.device)
+		bad = [torch.zeros((1,), dtype=torch.int32, device=xd.device)]
 
-		for K in range(nblk):
+		# persistent double buffers for the panel operands (allocated once on the caller's stream, so the
+		# caching allocator never recycles them while the other stream still reads them)
+		prow_buf = [ops.empty(max(nr * NB, 1), NB) for _ in range(2)]
+		pcol_buf = [ops.empty(max(nc * NB, 1), NB) for _ in range(2)]
+
+		def panel_step(K, slot):
+			"""Steps 1-4 of the header for block column K on the CURRENT stream: diagonal factor + its
+			broadcast, local panel solve, row broadcast, column exchange.  Fills the slot's prow / pcol."""
 			kr, kc, lkr, lkc = K % Pr, K % Pc, K // Pr, K // Pc
 			i0 = self._first_local_above(K, myr, Pr)
 			j0 = self._first_local_above(K, myc, Pc)
 			rows_below, cols_right = (nr - i0) * NB, (nc - j0) * NB
-			prow = ops.empty(max(rows_below, 0), NB)
+			prow = prow_buf[slot][:max(rows_below, 0)]
+			pcol = pcol_buf[slot][:max(cols_right, 0)]
 			if myc == kc:
 				winv_elems = (NB // IB) * IB * IB
 				dpack = ops.empty(NB * NB + winv_elems)          # [L_KK | inverse 128-blocks of L_KK]
 				if myr == kr:
 					D = Aloc[lkr * NB:(lkr + 1) * NB, lkc * NB:(lkc + 1) * NB]
 					winv, info = ops.potrf(D)
-					bad = torch.maximum(bad, torch.where(info > 0, info + K * NB, info))
+					bad[0] = torch.maximum(bad[0], torch.where(info > 0, info + K * NB, info))
 					dpack[:NB * NB].copy_(D.reshape(-1))
 					dpack[NB * NB:].copy_(winv)
 				self._bcast(dpack, self._rank_of(kr, kc), self.col_groups[kc], Pr)
@@ -279,7 +287,6 @@ class DistributedGaussianProcess:
 			if rows_below > 0:
 				self._bcast(prow, self._rank_of(myr, kc), self.row_groups[myr], Pc)
 			# column operand: L_JK for this rank's local block columns J > K
-			pcol = ops.empty(max(cols_right, 0), NB)
 			for rp in range(Pr):
 				Js = [J for J in range(K + 1, nblk) if J % Pc == myc and J % Pr == rp]
 				if not Js:
@@ -293,8 +300,45 @@ class DistributedGaussianProcess:
 				self._bcast(buf, self._rank_of(rp, myc), self.col_groups[myc], Pr)
 				dst = torch.tensor([J // Pc - j0 for J in Js], device=xd.device)
 				pcol.reshape(-1, NB, NB).index_copy_(0, dst, buf.reshape(-1, NB, NB))
-			if rows_below > 0 and cols_right > 0:
-				ops.gemm_nt(prow, pcol, Aloc[i0 * NB:, j0 * NB:], 1, bc=(NB, Pr, Pc, myr, myc, i0, j0))
+			return i0, j0, prow, pcol
+
+		# One block column of look-ahead: after panel K is in place, the local update of block column
+		# K+1 goes first; then panel K+1 (diagonal factor, solves and ALL its broadcasts) runs on a side
+		# stream while this stream applies panel K to the remaining columns.  Collectives are issued
+		# in the same program order on every rank.  On CPU tensors (tests) there are no streams and the
+		# same statements simply run in order.
+		on_gpu = xd.is_cuda
+		main = torch.cuda.current_stream() if on_gpu else None
+		side = torch.cuda.Stream(priority=-1) if on_gpu else None
+		ev_col = torch.cuda.Event() if on_gpu else None
+		ev_panel = torch.cuda.Event() if on_gpu else None
+
+		cur = panel_step(0, 0)
+		for K in range(nblk):
+			i0, j0, prow, pcol = cur
+			if K + 1 >= nblk:
+				break
+			rows_below = prow.shape[0]
+			nxt_c = (K + 1) % Pc
+			j1 = self._first_local_above(K + 1, myc, Pc)             # first local block column beyond K+1
+			if myc == nxt_c and rows_below > 0:                      # this rank owns (part of) block column K+1
+				jc = (K + 1) // Pc
+				ops.gemm_nt(prow, pcol[(jc - j0) * NB:(jc - j0 + 1) * NB], Aloc[i0 * NB:, jc * NB:(jc + 1) * NB], 1,
+							bc=(NB, Pr, Pc, myr, myc, i0, jc))
+			if on_gpu:
+				ev_col.record(main)
+			# the remaining columns: compute only, enqueued before the (possibly host-blocking) collectives below
+			if rows_below > 0 and nc - j1 > 0:
+				ops.gemm_nt(prow, pcol[(j1 - j0) * NB:], Aloc[i0 * NB:, j1 * NB:], 1, bc=(NB, Pr, Pc, myr, myc, i0, j1))
+			if on_gpu:
+				with torch.cuda.stream(side):
+					side.wait_event(ev_col)
+					cur = panel_step(K + 1, (K + 1) % 2)
+					ev_panel.record(side)
+				main.wait_event(ev_panel)
+			else:
+				cur = panel_step(K + 1, (K + 1) % 2)
+		bad = bad[0]
 
 		self._allreduce(bad, dist.ReduceOp.MAX)
 		if int(bad.item()) != 0:
