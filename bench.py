@@ -73,7 +73,7 @@ def main():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--n", type=int, default=65536)
+	ap.add_argument("--n", "--train-points", dest="n", type=int, default=65536)
 	ap.add_argument("--d", type=int, default=16)
 	ap.add_argument("--m", type=int, default=4096)
 	ap.add_argument("--nb", type=int, default=0)
@@ -86,11 +86,19 @@ def main():
 	if world != args.gpus:
 		if world == 1 and args.gpus > 1:
 			raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+	# STPY_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box: the ranks share card 0 and the
+	# collectives are staged through the host (functional check of this script only, not a measurement)
+	backend = os.environ.get("STPY_BENCH_BACKEND", "nccl")
+	if backend != "nccl":
+		local_rank = local_rank % max(torch.cuda.device_count(), 1)
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
 	if world > 1:
 		import torch.distributed as dist
-		dist.init_process_group(backend="nccl", device_id=dev)
+		if backend == "nccl":
+			dist.init_process_group(backend="nccl", device_id=dev)
+		else:
+			dist.init_process_group(backend=backend)
 
 	from stpy_amd import GaussianProcess, _lib
 	lib = _lib.load()
@@ -126,7 +134,7 @@ def main():
 	elapsed = time.perf_counter() - t0
 	lib.stpy_profile_enable(0)
 	if world > 1:
-		tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+		tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
 		torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
 		elapsed = float(tt.item())
 	sec_per_step = elapsed / args.steps
@@ -136,14 +144,16 @@ def main():
 		ms, fl, cnt = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
 		_lib.check(lib.stpy_profile_read(tag, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt)), "stpy_profile_read")
 		return ms.value, fl.value, cnt.value
-	tags = {"syrk": 0, "panel_gemm": 1, "trsm_gemm": 2, "potf2": 3}
+	tags = {"syrk": 0, "panel_gemm": 1, "trsm_gemm": 2, "potf2": 3, "gemm_api": 4}
 	pr = {k: prof(v) for k, v in tags.items()}
-	g_ms = pr["syrk"][0] + pr["panel_gemm"][0] + pr["trsm_gemm"][0]
-	g_fl = pr["syrk"][1] + pr["panel_gemm"][1] + pr["trsm_gemm"][1]
-	g_cnt = pr["syrk"][2] + pr["panel_gemm"][2] + pr["trsm_gemm"][2]
+	# the block-cyclic path issues its trailing updates through stpy_gemm_nt_bc (tag 4)
+	gemm_tags = ["syrk", "panel_gemm", "trsm_gemm"] + (["gemm_api"] if world > 1 else [])
+	g_ms = sum(pr[t][0] for t in gemm_tags)
+	g_fl = sum(pr[t][1] for t in gemm_tags)
+	g_cnt = sum(pr[t][2] for t in gemm_tags)
 	# launches on the look-ahead stream overlap the trailing update: time them as the union of intervals
 	ub, uf, uc = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-	_lib.check(lib.stpy_profile_read_union(0b0111, ctypes.byref(ub), ctypes.byref(uf), ctypes.byref(uc)), "stpy_profile_read_union")
+	_lib.check(lib.stpy_profile_read_union(0b0111 if world == 1 else 0b10111, ctypes.byref(ub), ctypes.byref(uf), ctypes.byref(uc)), "stpy_profile_read_union")
 	achieved = uf.value / (ub.value * 1e-3) / 1e12 if ub.value > 0 else 0.0
 
 	# HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
@@ -165,9 +175,9 @@ def main():
 			"metric": "GP fit+mean_var wall-time (s), N=%d d=%d fp64" % (n, d),
 			"value": round(sec_per_step, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
 			"ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": False,
-			"scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+			"scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: %s backend, ranks share one GPU)" % backend,
 			"config": {"workload": "GaussianProcess.fit_gp + mean_std, SE kernel gamma=sqrt(d), s=0.1, N=%d train, M=%d test, d=%d, fp64" % (n, m, d),
-					   "n": n, "m": m, "d": d, "nb": args.nb or "potrf 1024, trsm 512 (library defaults)",
+					   "n": n, "m": m, "d": d, "nb": args.nb or ("potrf 1024, trsm 512 (library defaults)" if world == 1 else "distribution block %d" % gp.NB),
 					   "parallelism": "single GPU" if world == 1 else "2-D block-cyclic over %d GPUs" % world},
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),

@@ -134,6 +134,19 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k,
                  void* C, int64_t ldc, int mode, int lower_only, void* stream);
 
 /*
+ * The same product when C has few 128x128 tiles but k is long (the left-looking partial sums of the
+ * distributed solve, gauss_procc.py:368-378 on a sharded factor): the K range is cut into `passes`
+ * pieces that run as separate workgroups into `work` (passes*m*n elements, caller-owned) and are
+ * then summed into C in a fixed order.  stpy_gemm_nt_splitk_passes recommends the number of passes
+ * (1 = use stpy_gemm_nt).  m <= 8 never needs this: stpy_gemm_nt takes a bandwidth-bound row
+ * kernel for such products.
+ */
+int stpy_gemm_nt_splitk_passes(int64_t m, int64_t n, int64_t k);
+int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k,
+                        const void* A, int64_t lda, const void* B, int64_t ldb,
+                        void* C, int64_t ldc, int mode, int passes, void* work, void* stream);
+
+/*
  * The same contraction on a window of a rank's LOCAL matrix under a 2-D block-cyclic distribution
  * (multi-GPU trailing update): distribution block nb_dist (multiple of 128), process grid pr x pc,
  * this rank (myr, myc); the window starts at local block (i0, j0).  A 128x128 tile in local block

@@ -186,6 +186,24 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int6
 	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, lower_only, st));
 }
 
+int stpy_gemm_nt_splitk_passes(int64_t m, int64_t n, int64_t k)
+{
+	return gemm_splitk_plan(m, n, k);
+}
+
+int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
+                        void* C, int64_t ldc, int mode, int passes, void* work, void* stream)
+{
+	if (!A || !B || !C) { set_error("stpy_gemm_nt_splitk: null pointer"); return -5; }
+	if (passes > 1 && !work) { set_error("stpy_gemm_nt_splitk: %d passes need a workspace of passes*m*n elements", passes); return -5; }
+	if (mode != 0 && mode != 1) { set_error("stpy_gemm_nt_splitk: mode must be 0 or 1"); return -11; }
+	hipStream_t st = (hipStream_t)stream;
+	ProfScope ps(TAG_GEMM_API, 2.0 * (double)m * (double)n * (double)k, st);
+	DISPATCH(dtype,
+	         gemm_nt<double>(m, n, k, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, (double*)nullptr, 0, mode, 0, st, nullptr, nullptr, nullptr, passes, (double*)work),
+	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, 0, st, nullptr, nullptr, nullptr, passes, (float*)work));
+}
+
 int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
                     void* C, int64_t ldc, int mode, int nb_dist, int pr, int pc, int myr, int myc, int i0, int j0, void* stream)
 {

@@ -65,7 +65,8 @@ template <typename T> struct GramEpilogue { int kind, combine; T kappa, offset, 
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
-            const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr);
+            const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr, int ksplit = 1, T* split_work = nullptr);
+int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);      // recommended number of K passes for a product with few output tiles
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st);
 template <typename T>

@@ -62,6 +62,9 @@ struct GemmArgs {
 	// with I < J (strictly above the global diagonal) are skipped.  bc_nbt == 0: off.
 	int bc_nbt, bc_pr, bc_pc, bc_myr, bc_myc, bc_i0, bc_j0;
 	int exp;                 // timing experiments (0 in production)
+	// split-K (few output tiles, long K): the super-tile range is enumerated ksplit times; pass s
+	// contracts K range [s*kchunk, (s+1)*kchunk) into the partial result at C + s*split_stride
+	int ksplit, kchunk; int64_t split_stride;
 };
 
 // Random-Fourier-feature epilogue: scale * cos(q + b) or scale * sin(q).  fp64: libm-accurate.
@@ -158,9 +161,14 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// ---- block -> tile.  Blocks b, b+8, b+16.. share an XCD (round-robin dispatch; speed only):
 	// ---- super-tile S = (b % 8) + 8 * (b / 512), tile within it = (b / 8) % 64.
 	const int b = blockIdx.x;
-	const int S = (b & 7) + 8 * (b >> 9);
+	int S = (b & 7) + 8 * (b >> 9);
 	const int w = (b >> 3) & 63;
-	if (S >= p.nsuper) return;
+	int split = 0;
+	if (p.ksplit > 1) {
+		split = __builtin_amdgcn_readfirstlane(S / p.nsuper);
+		S -= split * p.nsuper;
+		if (split >= p.ksplit) return;
+	} else if (S >= p.nsuper) return;
 	int si, sj;
 	if (p.tri) {
 		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
@@ -184,6 +192,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	}
 
 	const int row0 = ti * BM, col0 = tj * BN;
+	const int kbeg = p.kskip ? row0 : split * p.kchunk;        // (multiples of the tile size, so K tiles stay aligned)
+	const int kend = p.ksplit > 1 ? min(p.k, kbeg + p.kchunk) : p.k;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int wm = wave >> 1, wn = wave & 1;
 	const int r16 = lane & 15, g = lane >> 4;
@@ -204,7 +214,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 				for (int e = 0; e < CH; ++e) {
 					const int kk = k0 + lch * CH + e;
-					const bool ok = kk < p.k;
+					const bool ok = kk < kend;
 					const int kc = ok ? kk : 0;
 					T va = p.A[(int64_t)ar * p.lda + kc];
 					T vb = p.B[(int64_t)br * p.ldb + kc];
@@ -270,8 +280,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		}
 	}
 
-	const int kbeg = p.kskip ? row0 : 0;        // (multiple of the tile size, so K tiles stay aligned)
-	const int KT = (p.k - kbeg + BK - 1) / BK;
+	const int KT = (kend - kbeg + BK - 1) / BK;
 	if (DMA) dma_issue(0, kbeg);
 	else gload(kbeg);
 
@@ -280,7 +289,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// Addressing: uniform tile base (SGPRs) + one 32-bit element offset per accumulator row; the
 	// four column tiles of a row are immediate offsets, so 16 VGPRs address all 64 elements.
 	v4 acc[4][4];
-	T* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
+	T* const ctile = p.C + (int64_t)split * p.split_stride + (int64_t)row0 * p.ldc + col0;
 	const unsigned ldc32 = (unsigned)p.ldc;
 #pragma unroll
 	for (int tm = 0; tm < 4; ++tm)
@@ -525,15 +534,106 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	}
 }
 
+// ---- C (=, -=) sum over the split-K partial products (fixed order: the result does not depend on scheduling)
+template <typename T>
+__global__ __launch_bounds__(256)
+void splitk_reduce_kernel(const T* __restrict__ work, int splits, int64_t m, int64_t n, T* __restrict__ C, int64_t ldc, int mode)
+{
+	const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (e >= m * n) return;
+	T sum = T(0);
+	for (int s = 0; s < splits; ++s) sum += work[(int64_t)s * m * n + e];
+	T* c = C + (e / n) * ldc + (e % n);
+	*c = mode == 1 ? *c - sum : sum;
+}
+
+// ---- skinny product: m <= SKINNY_MAX rows of A against all n rows of B (a handful of right-hand
+// ---- sides through the distributed solve, z = L^-1 y).  HBM-bound on B: one workgroup per row of
+// ---- B, its four waves stream interleaved 16-byte chunks of the row, A stays in L2.  The sum order is
+// ---- fixed by the thread layout.
+constexpr int SKINNY_MAX = 8;
+template <typename T, int MR, bool VEC>
+__global__ __launch_bounds__(256)
+void gemm_skinny_kernel(int m, int64_t k, const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                        T* __restrict__ C, int64_t ldc, int mode)
+{
+	constexpr int CH = 16 / sizeof(T);
+	typedef T vch __attribute__((ext_vector_type(CH)));
+	const int j = blockIdx.x, tid = threadIdx.x;
+	const T* brow = B + (int64_t)j * ldb;
+	T acc[MR];
+#pragma unroll
+	for (int i = 0; i < MR; ++i) acc[i] = T(0);
+	if (VEC) {
+		for (int64_t kk = (int64_t)tid * CH; kk < k; kk += 256 * CH) {
+			const vch b = *(const vch*)(brow + kk);
+#pragma unroll
+			for (int i = 0; i < MR; ++i) {
+				const vch a = *(const vch*)(A + (int64_t)min(i, m - 1) * lda + kk);
+#pragma unroll
+				for (int e = 0; e < CH; ++e) acc[i] = fma(a[e], b[e], acc[i]);
+			}
+		}
+	} else {
+		for (int64_t kk = tid; kk < k; kk += 256) {
+			const T b = brow[kk];
+#pragma unroll
+			for (int i = 0; i < MR; ++i) acc[i] = fma(A[(int64_t)min(i, m - 1) * lda + kk], b, acc[i]);
+		}
+	}
+	__shared__ T red[4][MR];
+#pragma unroll
+	for (int i = 0; i < MR; ++i) {
+		T v = acc[i];
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+		if ((tid & 63) == 0) red[tid >> 6][i] = v;
+	}
+	__syncthreads();
+	if (tid < m) {
+		const T sum = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+		T* c = C + (int64_t)tid * ldc + j;
+		*c = mode == 1 ? *c - sum : sum;
+	}
+}
+
+template <typename T>
+static int gemm_skinny(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb, T* C, int64_t ldc, int mode, hipStream_t st)
+{
+	if (n > INT32_MAX) { set_error("gemm_nt: dimension exceeds int32"); return -2; }
+	constexpr int CH = 16 / sizeof(T);
+	const bool vec = (k % CH == 0) && (lda % CH == 0) && (ldb % CH == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
+	const dim3 grid((unsigned)n), block(256);
+#define STPY_SK(MR) do { if (vec) hipLaunchKernelGGL((gemm_skinny_kernel<T, MR, true>), grid, block, 0, st, (int)m, k, A, lda, B, ldb, C, ldc, mode); \
+                         else hipLaunchKernelGGL((gemm_skinny_kernel<T, MR, false>), grid, block, 0, st, (int)m, k, A, lda, B, ldb, C, ldc, mode); } while (0)
+	if (m == 1) STPY_SK(1);
+	else if (m <= 2) STPY_SK(2);
+	else if (m <= 4) STPY_SK(4);
+	else STPY_SK(8);
+#undef STPY_SK
+	return check_launch("gemm_nt (skinny)");
+}
+
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc, const RffEpilogue<T>* rff,
-            const GramEpilogue<T>* gr)
+            const GramEpilogue<T>* gr, int ksplit, T* split_work)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (k <= 0) {
 		if (mode == 0) { set_error("gemm_nt: k == 0 with overwrite mode is not supported"); return -4; }
 		return 0;
+	}
+	const bool plain = (mode == 0 || mode == 1) && !lower_only && !bc && !C2;
+	// (the block solve multiplies a row block by an inverse diagonal block IN PLACE, C == A: fine for the
+	// tile kernel, whose single column of tiles reads its rows of A before storing, not for a kernel
+	// that finishes one column of C at a time)
+	if (plain && m <= SKINNY_MAX && (const T*)C != A && (const T*)C != B) return gemm_skinny<T>(m, n, k, A, lda, B, ldb, C, ldc, mode, st);
+	int64_t kchunk = 0;
+	if (ksplit > 1) {
+		if (!plain || !split_work) { set_error("gemm_nt: split-K needs a plain product (modes 0/1) and a workspace"); return -12; }
+		kchunk = ((k + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+		ksplit = (int)((k + kchunk - 1) / kchunk);          // every pass starts inside [0, k)
 	}
 	if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) { set_error("gemm_nt: dimension exceeds int32"); return -2; }
 	GemmArgs<T> p;
@@ -560,6 +660,13 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		if (m != n || m % BM != 0 && false) { set_error("gemm_nt: kskip needs a square problem"); return -12; }
 		p.kskip = 1;
 	}
+	p.ksplit = 1; p.kchunk = 0; p.split_stride = 0;
+	if (ksplit > 1) {       // partial products go to the packed workspace [ksplit][m][n]; summed below
+		p.ksplit = ksplit;
+		p.kchunk = (int)kchunk;
+		p.split_stride = m * n;
+		p.C = split_work; p.ldc = n;
+	}
 	p.exp = g_gemm_exp;
 	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
 	p.bc_nbt = 0; p.bc_pr = p.bc_pc = 1; p.bc_myr = p.bc_myc = p.bc_i0 = p.bc_j0 = 0;
@@ -577,7 +684,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.nst_m = (p.tiles_m + p.st_m - 1) / p.st_m;
 	p.nst_n = (p.tiles_n + p.st_n - 1) / p.st_n;
 	p.nsuper = p.tri ? p.nst_m * (p.nst_m + 1) / 2 : p.nst_m * p.nst_n;
-	const int64_t nblocks = (int64_t)((p.nsuper + 7) / 8) * 512;
+	const int64_t nblocks = (int64_t)(((int64_t)p.nsuper * p.ksplit + 7) / 8) * 512;
 	if (nblocks > INT32_MAX) { set_error("gemm_nt: grid too large"); return -2; }
 	// Workgroups of one launch all take the same time, so the two that share a CU would reach
 	// their memory-bound prologue/epilogue together, round after round, and the MFMA pipes would
@@ -594,7 +701,13 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
-	if (mode == 1) { if (aligned) STPY_LAUNCH(false, true, 0); else STPY_LAUNCH(true, true, 0); }
+	if (p.ksplit > 1) {
+		if (aligned) STPY_LAUNCH(false, false, 0); else STPY_LAUNCH(true, false, 0);
+		const int64_t total = m * n;
+		hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+		                   (const T*)split_work, p.ksplit, m, n, C, ldc, mode);
+	}
+	else if (mode == 1) { if (aligned) STPY_LAUNCH(false, true, 0); else STPY_LAUNCH(true, true, 0); }
 	else if (mode == 0) { if (aligned) STPY_LAUNCH(false, false, 0); else STPY_LAUNCH(true, false, 0); }
 	else if (mode == 3) { if (aligned) STPY_LAUNCH(false, false, 3); else STPY_LAUNCH(true, false, 3); }
 	else if (mode == 4) { if (aligned) STPY_LAUNCH(false, false, 4); else STPY_LAUNCH(true, false, 4); }
@@ -606,7 +719,19 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	return check_launch("gemm_nt");
 }
 
-template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*, const GramEpilogue<double>*);
-template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*, const GramEpilogue<float>*);
+template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*, const GramEpilogue<double>*, int, double*);
+template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*, const GramEpilogue<float>*, int, float*);
+
+int gemm_splitk_plan(int64_t m, int64_t n, int64_t k)
+{
+	// enough workgroups for two per CU on 256 CUs, at least 64 K-tiles (1024 deep) per pass
+	const int64_t tiles = ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
+	if (m <= SKINNY_MAX || tiles >= 384) return 1;
+	int64_t s = (512 + tiles - 1) / tiles;
+	const int64_t smax = k / 1024;
+	if (s > smax) s = smax;
+	if (s > 16) s = 16;
+	return s < 2 ? 1 : (int)s;
+}
 
 }  // namespace stpy

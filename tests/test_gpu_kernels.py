@@ -46,6 +46,44 @@ def test_gemm_nt(L, m, n, k, mode):
 	assert rel_err(Cd.cpu().numpy(), ref) < 1e-14 * max(1, k) ** 0.5 * 10
 
 
+@pytest.mark.parametrize("m,n,k,mode", [(1, 512, 4096, 0), (1, 300, 1001, 1), (2, 128, 640, 0), (3, 257, 96, 1), (5, 64, 2048, 0), (8, 512, 1536, 1)])
+def test_gemm_nt_skinny_rows(L, m, n, k, mode):
+	"""m <= 8 goes to the bandwidth-bound row kernel (z = L^-1 y on the distributed path)."""
+	rng = np.random.RandomState(m * 11 + n + k)
+	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+	Ad, Bd, Cd = dev(A), dev(B), dev(C)
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr()), "gemm")
+	ref = A @ B.T if mode == 0 else C - A @ B.T
+	assert rel_err(Cd.cpu().numpy(), ref) < 1e-13
+
+
+@pytest.mark.parametrize("m,n,k,mode,passes", [(256, 128, 4096, 0, 4), (512, 256, 3000, 1, 3), (130, 100, 2500, 0, 5), (128, 128, 1024, 1, 16)])
+def test_gemm_nt_splitk(L, m, n, k, mode, passes):
+	rng = np.random.RandomState(m + n + k + passes)
+	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+	Ad, Bd, Cd = dev(A), dev(B), dev(C)
+	work = torch.full((passes * m * n,), float("nan"), dtype=torch.float64, device="cuda:0")
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, passes, L.ptr(work), L.stream_ptr()), "splitk")
+	ref = A @ B.T if mode == 0 else C - A @ B.T
+	assert rel_err(Cd.cpu().numpy(), ref) < 1e-13
+	# the same call twice gives the same bits (fixed summation order)
+	Cd2 = dev(C)
+	L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd2), n, mode, passes, L.ptr(work), L.stream_ptr()), "splitk")
+	assert torch.equal(Cd, Cd2)
+
+
+def test_gemm_nt_splitk_plan(L):
+	lib = L.load()
+	assert lib.stpy_gemm_nt_splitk_passes(4096, 512, 32768) >= 2        # 128 tiles, long K
+	assert lib.stpy_gemm_nt_splitk_passes(4096, 512, 512) == 1          # short K
+	assert lib.stpy_gemm_nt_splitk_passes(8192, 8192, 65536) == 1       # plenty of tiles
+	assert lib.stpy_gemm_nt_splitk_passes(1, 512, 65536) == 1           # row kernel instead
+	assert lib.stpy_gemm_nt_splitk(L.F64, 256, 256, 4096, 1, 4096, 1, 4096, 1, 256, 0, 4, None, None) != 0
+	assert b"workspace" in lib.stpy_last_error_string()
+
+
 def test_gemm_nt_asymmetric_layout(L):
 	"""A = I with an asymmetric B: catches a transposed C/D fragment map (cdna guide section 3)."""
 	n = 128
