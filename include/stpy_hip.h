@@ -37,7 +37,9 @@ enum {
 	STPY_K_MATERN12 = 1,  /* kappa * exp(-r)                          kernels.py:844-845                 */
 	STPY_K_MATERN32 = 2,  /* kappa * (1+sqrt3 r) exp(-sqrt3 r)        kernels.py:846-848                 */
 	STPY_K_MATERN52 = 3,  /* kappa * (1+sqrt5 r+5r^2/3) exp(-sqrt5 r) kernels.py:849-851, :946-962       */
-	STPY_K_LINEAR = 4     /* kappa * <b_j, a_i> + offset              kernels.py:300-320                 */
+	STPY_K_LINEAR = 4,    /* kappa * <b_j, a_i> + offset              kernels.py:300-320                 */
+	STPY_K_POLY = 5       /* kappa * (<b_j, a_i> + offset)^p          kernels.py:744-761 (offset = 1 there);
+	                         the degree p (1..64) rides above the family byte: kind = STPY_K_POLY | (p << 8) */
 };
 
 /* how a kernel evaluation is combined into `out` -- the + and * kernel algebra of kernels.py:146-157 */

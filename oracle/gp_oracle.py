@@ -107,7 +107,77 @@ def linear(a, b, kappa=1.0, offset=0.0, group=None):
 	return kappa * (b @ a.T) + offset
 
 
+def ard_additive(a, b, ard_gamma, groups, kappa=1.0, group=None):
+	"""kernels.py:697-725 -- mean over the column groups of ard kernels; the columns are first
+	subset by ``group``, each entry of ``groups`` then indexes that subset (and ard_gamma)."""
+	a = _cols(a, group)
+	b = _cols(b, group)
+	r = np.zeros((b.shape[0], a.shape[0]))
+	for g in groups:
+		r = r + ard(a, b, ard_gamma, kappa, g)
+	return r / float(len(groups))
+
+
+def squared_exponential_per_group(a, b, groups, gamma_per_group, kappa=1.0, inner_kappa=1.0):
+	"""kernels.py:669-695 -- kappa * mean_g SE(group g, gamma_g); each SE term applies kappa itself
+	as well (the object's, or the overriding one), so the constant enters twice."""
+	r = np.zeros((np.asarray(b).shape[0], np.asarray(a).shape[0]))
+	for g, gamma in zip(groups, gamma_per_group):
+		r = r + squared_exponential(a, b, float(gamma), inner_kappa, g)
+	return kappa * r / float(len(groups))
+
+
+def ard_per_group(a, b, groups, ard_per_group_gamma, kappa=1.0):
+	"""kernels.py:620-667 -- consecutive slices of the lengthscale vector belong to consecutive groups."""
+	gam = np.asarray(ard_per_group_gamma, dtype=np.float64).reshape(-1)
+	a = np.asarray(a, dtype=np.float64)
+	b = np.asarray(b, dtype=np.float64)
+	r = np.zeros((b.shape[0], a.shape[0]))
+	idx = 0
+	for g in groups:
+		gl = gam[idx:idx + len(g)]
+		idx += len(g)
+		ax = a[:, list(g)] / gl
+		bx = b[:, list(g)] / gl
+		normx = np.sum(ax ** 2, axis=1).reshape(-1, 1)
+		normy = np.sum(bx ** 2, axis=1).reshape(-1, 1)
+		r = r + np.exp(-0.5 * (-2 * (bx @ ax.T) + normx.T + normy))
+	return kappa * r / float(len(groups))
+
+
+def full_covariance_se(a, b, cov, kappa=1.0, group=None):
+	"""kernels.py:464-498 -- points mapped by the (square-root covariance) matrix, then SE with gamma = 1."""
+	cov = np.asarray(cov, dtype=np.float64)
+	a = _cols(a, group) @ cov
+	b = _cols(b, group) @ cov
+	normx = np.sum(a ** 2, axis=1).reshape(-1, 1)
+	normy = np.sum(b ** 2, axis=1).reshape(-1, 1)
+	return kappa * np.exp(-0.5 * (-2 * (b @ a.T) + normx.T + normy))
+
+
+def full_covariance_matern(a, b, cov, nu=1.5, kappa=1.0, group=None):
+	"""kernels.py:501-549 -- the same map, then Euclidean distances (torch.cdist) into the Matern forms."""
+	cov = np.asarray(cov, dtype=np.float64)
+	a = _cols(a, group) @ cov
+	b = _cols(b, group) @ cov
+	return kappa * _matern_of_dist(cdist(a, b, metric='euclidean').T, nu)
+
+
+def polynomial(a, b, degree=2, kappa=1.0, group=None):
+	"""kernels.py:744-761 -- kappa * (<b, a> + 1)^degree."""
+	a = _cols(a, group)
+	b = _cols(b, group)
+	return kappa * (b @ a.T + 1) ** degree
+
+
 _KERNELS = {
+	"ard_additive": lambda a, b, p: ard_additive(a, b, p["ard_gamma"], p["groups"], p.get("kappa", 1.0), p.get("group")),
+	"squared_exponential_per_group": lambda a, b, p: squared_exponential_per_group(a, b, p["groups"], p["gamma_per_group"], p.get("kappa", 1.0),
+																					 p.get("inner_kappa", p.get("kappa", 1.0))),
+	"ard_per_group": lambda a, b, p: ard_per_group(a, b, p["groups"], p["ard_per_group"], p.get("kappa", 1.0)),
+	"full_covariance_se": lambda a, b, p: full_covariance_se(a, b, p["cov"], p.get("kappa", 1.0), p.get("group")),
+	"full_covariance_matern": lambda a, b, p: full_covariance_matern(a, b, p["cov"], p.get("nu", 1.5), p.get("kappa", 1.0), p.get("group")),
+	"polynomial": lambda a, b, p: polynomial(a, b, p.get("degree", 2), p.get("kappa", 1.0), p.get("group")),
 	"squared_exponential": lambda a, b, p: squared_exponential(a, b, p.get("gamma", 1.0), p.get("kappa", 1.0), p.get("group")),
 	"ard": lambda a, b, p: ard(a, b, p["ard_gamma"], p.get("kappa", 1.0), p.get("group")),
 	"matern": lambda a, b, p: matern(a, b, p.get("gamma", 1.0), p.get("nu", 1.5), p.get("kappa", 1.0), p.get("group")),

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstpy_hip.so")
 
 F64, F32 = 0, 1
-K_SE, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR = 0, 1, 2, 3, 4
+K_SE, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR, K_POLY = 0, 1, 2, 3, 4, 5
 OUT_SET, OUT_ADD, OUT_MUL = 0, 1, 2
 IB = 128
 

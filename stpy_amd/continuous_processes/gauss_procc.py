@@ -441,8 +441,10 @@ class GaussianProcess:
 		n = L.shape[0]
 		dt = _lib.dtype_code(L.dtype)
 		it = kernel._resolve(dict(X) if X else {})[0]
-		if it['kind'] == _lib.K_LINEAR:
-			raise NotImplementedError("the linear kernel has no lengthscale gradient")
+		if len(it['terms']) != 1 or it['premap'] is not None:
+			raise NotImplementedError("evidence gradients are provided for single-term kernels (no additive groups / full covariance yet)")
+		if (it['kind'] & 0xff) in (_lib.K_LINEAR, _lib.K_POLY):
+			raise NotImplementedError("dot-product kernels have no lengthscale gradient")
 		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
 		st = _lib.stream_ptr
 		alpha = self._backward_z(L, winv, z)

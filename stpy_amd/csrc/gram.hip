@@ -24,12 +24,20 @@ struct GramArgs {
 	int64_t lda, ldb, ldo;
 	int n, q, d;
 	T kappa, offset, diag_add;
-	int kind, lower_only, combine;
+	int kind, lower_only, combine, degree;
 };
 
-template <typename T> __device__ __forceinline__ T phi(int kind, T acc, T na, T nb)
+template <typename T> __device__ __forceinline__ T int_power(T base, int degree)
+{
+	T r = T(1);
+	for (int e = 0; e < degree; ++e) r *= base;
+	return r;
+}
+
+template <typename T> __device__ __forceinline__ T phi(int kind, T acc, T na, T nb, T offset, int degree)
 {
 	switch (kind) {
+	case STPY_K_POLY: return int_power(acc + offset, degree);           // (<b,a> + c)^p, kernels.py:760
 	case STPY_K_SE: {
 		const T sq = na + nb - T(2) * acc;
 		return exp(T(-0.5) * sq);
@@ -127,8 +135,8 @@ void gram_kernel(GramArgs<T> p)
 		const int gj = j0 + jr + r;
 		if (gj >= p.q) break;
 		const T nb = DIRECT ? T(0) : nb_s[jr + r];
-		T v0 = p.kappa * phi<T>(p.kind, acc[r][0], na0, nb);
-		T v1 = p.kappa * phi<T>(p.kind, acc[r][1], na1, nb);
+		T v0 = p.kappa * phi<T>(p.kind, acc[r][0], na0, nb, p.offset, p.degree);
+		T v1 = p.kappa * phi<T>(p.kind, acc[r][1], na1, nb, p.offset, p.degree);
 		if (p.kind == STPY_K_LINEAR) { v0 += p.offset; v1 += p.offset; }
 		T* o = p.out + (int64_t)gj * p.ldo + gi;
 		if (p.combine == STPY_OUT_ADD) { if (gi < p.n) v0 += o[0]; if (gi + 1 < p.n) v1 += o[1]; }
@@ -186,6 +194,10 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
          int lower_only, int combine, T* out, int64_t ldo, void* work, hipStream_t st)
 {
 	if (n <= 0 || q <= 0) return 0;
+	const int degree = kind >> 8;           // STPY_K_POLY carries its degree above the family byte
+	kind &= 0xff;
+	if (kind == STPY_K_POLY && (degree < 1 || degree > 64)) { set_error("gram: polynomial degree %d out of range [1, 64]", degree); return -1; }
+	if (kind != STPY_K_POLY && degree != 0) { set_error("gram: unknown kernel kind %d", kind | (degree << 8)); return -1; }
 	if (work && kind != STPY_K_MATERN12 && kind >= STPY_K_SE && kind <= STPY_K_LINEAR) {
 		const int dpad = (d + 15) / 16 * 16;
 		char* w = (char*)work;
@@ -203,13 +215,13 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 		return gemm_nt<T>(q, n, dpad, bs, dpad, as, dpad, out, ldo, (T*)nullptr, 0, 3, lower_only, st, nullptr, nullptr, &epi);
 	}
 	if (n > INT32_MAX || q > INT32_MAX) { set_error("gram: dimension exceeds int32"); return -4; }
-	if (kind < STPY_K_SE || kind > STPY_K_LINEAR) { set_error("gram: unknown kernel kind %d", kind); return -1; }
+	if (kind < STPY_K_SE || kind > STPY_K_POLY) { set_error("gram: unknown kernel kind %d", kind); return -1; }
 	GramArgs<T> p;
 	p.a = a; p.b = b; p.cols = cols; p.inv_ls = inv_ls; p.out = out;
 	p.lda = lda; p.ldb = ldb; p.ldo = ldo;
 	p.n = (int)n; p.q = (int)q; p.d = d;
 	p.kappa = (T)kappa; p.offset = (T)offset; p.diag_add = (T)diag_add;
-	p.kind = kind; p.lower_only = lower_only; p.combine = combine;
+	p.kind = kind; p.lower_only = lower_only; p.combine = combine; p.degree = degree;
 	dim3 grid((unsigned)((n + GT_I - 1) / GT_I), (unsigned)((q + GT_J - 1) / GT_J));
 	if (grid.y > 65535u) { set_error("gram: q too large for one launch"); return -7; }
 	const bool direct = (kind == STPY_K_MATERN12 || kind == STPY_K_MATERN32 || kind == STPY_K_MATERN52);
@@ -238,7 +250,8 @@ int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_
 	return gemm_nt<T>(n, n, dpad, as, dpad, as, dpad, H, ldh, (T*)nullptr, 0, 4, 0, st, nullptr, nullptr, &epi);
 }
 
-// k(x_i, x_i): stationary kernels give kappa * phi(0); LINEAR gives kappa ||x_i[cols] * inv_ls||^2 + offset
+// k(x_i, x_i): stationary kernels give kappa * phi(0); LINEAR gives kappa ||x_i[cols] * inv_ls||^2 + offset,
+// POLY kappa (||x_i[cols] * inv_ls||^2 + offset)^degree
 template <typename T>
 __global__ void gram_diag_kernel(int kind, const T* __restrict__ x, int64_t m, int64_t ldx, int d, const int32_t* cols,
                                  const T* inv_ls, T kappa, T offset, int combine, T* __restrict__ out)
@@ -246,10 +259,12 @@ __global__ void gram_diag_kernel(int kind, const T* __restrict__ x, int64_t m, i
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= m) return;
 	T v;
-	if (kind == STPY_K_LINEAR) {
+	const int degree = kind >> 8;
+	kind &= 0xff;
+	if (kind == STPY_K_LINEAR || kind == STPY_K_POLY) {
 		T s = T(0);
 		for (int k = 0; k < d; ++k) { const T t = x[i * ldx + (cols ? cols[k] : k)] * inv_ls[k]; s += t * t; }
-		v = kappa * s + offset;
+		v = kind == STPY_K_LINEAR ? kappa * s + offset : kappa * int_power(s + offset, degree);
 	} else {
 		// -2<x,x> + ||x||^2 + ||x||^2 is exactly 0 in the reference's own evaluation order
 		v = kappa;

@@ -1,7 +1,8 @@
 """
 Drop-in for ``stpy.kernels.KernelFunction`` on the Gram-matrix hot path (reference:
 stpy/kernels.py:10-261 dispatcher, :136-159 ``kernel``, :368-398 SE, :552-583 ARD,
-:811-859 Matern, :917-970 ARD-Matern, :300-320 linear).
+:811-859 Matern, :917-970 ARD-Matern, :300-320 linear, :620-725 additive-group SE/ARD,
+:464-549 full-covariance SE / Matern, :744-761 polynomial).
 
 Same constructor arguments, same ``kernel(a, b, **kwargs) -> (|b|, |a|)`` orientation, same ``+`` /
 ``*`` algebra and the same kwargs-override protocol (``kernel(a, b, **{'0': {'gamma': g}})``) that
@@ -16,10 +17,9 @@ from . import _lib
 
 # kernel families implemented on the device; everything else in kernels.py:167-261 is outside
 # the hot path and raises.
-_SUPPORTED = ("squared_exponential", "ard", "matern", "ard_matern", "linear")
-_OUT_OF_SCOPE = ("laplace", "modified_matern", "custom", "tanh", "step", "angsim", "full_covariance_se",
-				 "full_covariance_matern", "polynomial", "squared_exponential_per_group", "ard_per_group",
-				 "gibbs", "gibbs_custom", "random_map")
+_SUPPORTED = ("squared_exponential", "ard", "matern", "ard_matern", "linear", "ard with groups", "squared_exponential_per_group",
+			  "ard_per_group", "full_covariance_se", "full_covariance_matern", "polynomial")
+_OUT_OF_SCOPE = ("laplace", "modified_matern", "custom", "tanh", "step", "angsim", "gibbs", "gibbs_custom", "random_map")
 
 _MATERN_KIND = {0.5: _lib.K_MATERN12, 1.5: _lib.K_MATERN32, 2.5: _lib.K_MATERN52}
 
@@ -102,7 +102,21 @@ class KernelFunction:
 			params = dict(**params, **{'gamma': self.gamma, 'nu': self.v})
 		elif name == "ard_matern":
 			params = dict(**params, **{'ard_gamma': self.ard_gamma, 'nu': self.v})
-		elif name in _OUT_OF_SCOPE or (name == "ard" and self.groups is not None):
+		elif name == "full_covariance_se":
+			params = dict(**params, **{'cov': self.cov})
+		elif name == "full_covariance_matern":
+			params = dict(**params, **{'cov': self.cov, 'nu': self.v})
+		elif name == "polynomial" and self.groups is None:
+			params = dict(**params, **{'degree': self.power})
+		elif name == "polynomial":
+			# kernels.py:763-788 subsets the columns of an already subset matrix with `group` again and
+			# raises for any proper grouping (pinned by tests/golden K2 'poly_additive_raises')
+			raise NotImplementedError("the additive polynomial kernel does not evaluate in the reference either (kernels.py:763-788)")
+		elif name == "ard":
+			params = dict(**params, **{'ard_gamma': self.ard_gamma, 'groups': self.groups})
+		elif name in ("squared_exponential_per_group", "ard_per_group") and self.groups is not None:
+			params = dict(**params, **{'groups': self.groups})
+		elif name in _OUT_OF_SCOPE:
 			raise NotImplementedError("kernel '%s' is outside the stpy_amd hot path (supported: %s)" % (name, ", ".join(_SUPPORTED)))
 		else:
 			raise AssertionError("Kernel not implemented.")     # kernels.py:261
@@ -174,29 +188,73 @@ class KernelFunction:
 			name = self.optkernel_list[i]
 			kappa = _scalar(arg['kappa']) if 'kappa' in arg else _scalar(owner.kappa)
 			group = list(arg['group']) if 'group' in arg else list(owner.group)
-			offset = 0.0
+
+			def term(kind, inv_ls, cols=None, k=None, offset=0.0, premap=None):
+				return dict(kind=kind, kappa=kappa if k is None else k, group=group if cols is None else list(cols), inv_ls=inv_ls,
+							offset=offset, premap=premap)
+
+			def vec(v):
+				return torch.as_tensor(v).detach().double().reshape(-1)
+
 			if name == "squared_exponential":
 				gamma = _scalar(arg['gamma']) if 'gamma' in arg else _scalar(owner.gamma)
-				kind, inv_ls = _lib.K_SE, [1.0 / gamma] * len(group)
+				terms = [term(_lib.K_SE, [1.0 / gamma] * len(group))]
+			elif name == "ard" and ('groups' in arg or owner.groups is not None):
+				# kernels.py:697-725: columns subset by `group`, every entry of `groups` then indexes that
+				# subset and ard_gamma; each term carries kappa, the mean is over the groups
+				g = vec(arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma)
+				groups = arg['groups'] if 'groups' in arg else owner.groups
+				terms = [term(_lib.K_SE, [1.0 / float(g[j]) for j in ga], cols=[group[j] for j in ga], k=kappa / len(groups)) for ga in groups]
 			elif name == "ard":
-				g = arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma
-				g = torch.as_tensor(g).detach().double().reshape(-1)
-				kind, inv_ls = _lib.K_SE, [1.0 / float(g[j]) for j in group]              # kernels.py:572
+				g = vec(arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma)
+				terms = [term(_lib.K_SE, [1.0 / float(g[j]) for j in group])]                 # kernels.py:572
+			elif name == "squared_exponential_per_group":
+				# kernels.py:669-695: kappa * mean_g SE_g, and SE_g applies kappa again (the overriding one
+				# if present, else the object's)
+				if 'gamma_per_group' not in arg:
+					raise AssertionError("This kernel requires 'gamma_per_group' initial parameters")
+				groups = arg['groups'] if 'groups' in arg else owner.groups
+				gpg = [_scalar(v) for v in arg['gamma_per_group']]
+				terms = [term(_lib.K_SE, [1.0 / gam] * len(ga), cols=ga, k=kappa * kappa / len(groups)) for ga, gam in zip(groups, gpg)]
+			elif name == "ard_per_group":
+				# kernels.py:620-667: consecutive slices of the lengthscale vector belong to consecutive groups
+				if 'ard_per_group' not in arg:
+					raise AssertionError("This kernel requires 'ard_per_group' initial parameters")
+				groups = arg['groups'] if 'groups' in arg else owner.groups
+				g = vec(arg['ard_per_group'])
+				terms, at = [], 0
+				for ga in groups:
+					terms.append(term(_lib.K_SE, [1.0 / float(v) for v in g[at:at + len(ga)]], cols=ga, k=kappa / len(groups)))
+					at += len(ga)
 			elif name == "matern":
 				gamma = _scalar(arg['gamma']) if 'gamma' in arg else _scalar(owner.gamma)
 				nu = arg['nu'] if 'nu' in arg else owner.v
-				kind, inv_ls = self._matern_kind(nu), [1.0 / gamma] * len(group)
+				terms = [term(self._matern_kind(nu), [1.0 / gamma] * len(group))]
 			elif name == "ard_matern":
-				g = arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma
-				g = torch.as_tensor(g).detach().double().reshape(-1)
+				g = vec(arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma)
 				nu = arg['nu'] if 'nu' in arg else owner.v
-				kind, inv_ls = self._matern_kind(nu), [1.0 / float(g[j]) for j in group]  # kernels.py:941
+				terms = [term(self._matern_kind(nu), [1.0 / float(g[j]) for j in group])]  # kernels.py:941
+			elif name in ("full_covariance_se", "full_covariance_matern"):
+				# kernels.py:464-549: x[:, group] @ cov, then SE (gamma = 1) / Matern on Euclidean distances;
+				# the Matern variant reads its smoothness from 'v' (not 'nu'), else the object's
+				cov = arg['cov'] if 'cov' in arg else owner.cov
+				cov = torch.as_tensor(cov).detach().double()
+				kind = _lib.K_SE if name == "full_covariance_se" else self._matern_kind(arg['v'] if 'v' in arg else owner.v)
+				terms = [term(kind, [1.0] * cov.shape[1], premap=cov)]
+			elif name == "polynomial":
+				degree = int(arg['degree'] if 'degree' in arg else owner.power)
+				if degree != (arg['degree'] if 'degree' in arg else owner.power) or degree < 1:
+					raise NotImplementedError("polynomial kernel: positive integer degrees only on the device")
+				terms = [term(_lib.K_POLY | (degree << 8), [1.0] * len(group), offset=1.0)]  # kernels.py:760: (<b,a> + 1)^p
 			elif name == "linear":
 				offset = _scalar(arg['offset']) if 'offset' in arg else _scalar(owner.offset)
-				kind, inv_ls = _lib.K_LINEAR, [1.0] * len(group)
+				terms = [term(_lib.K_LINEAR, [1.0] * len(group), offset=offset)]
 			else:
 				raise AssertionError("Kernel not implemented.")
-			items.append(dict(kind=kind, kappa=kappa, group=group, inv_ls=inv_ls, offset=offset, op=self.operations[i]))
+			item = dict(op=self.operations[i], terms=terms)
+			if len(terms) == 1:          # single-launch items keep the flat view the evidence-gradient code reads
+				item.update(terms[0])
+			items.append(item)
 		return items
 
 	@staticmethod
@@ -208,29 +266,75 @@ class KernelFunction:
 		return _MATERN_KIND[nu]
 
 	# ------------------------------------------------------------------ evaluation
+	@staticmethod
+	def _plan(items):
+		"""
+		Flattens the items into launches (term, target, combine).  An item is the SUM of its terms;
+		items are chained with the + / * algebra of kernels.py:146-157.  A multi-term item under "*"
+		is first summed into a scratch buffer ("tmp") and multiplied in afterwards.
+		"""
+		launches = []
+		for it in items:
+			comb = {"-": _lib.OUT_SET, "+": _lib.OUT_ADD, "*": _lib.OUT_MUL}[it['op']]
+			scratch = it['op'] == "*" and len(it['terms']) > 1
+			for t_i, t in enumerate(it['terms']):
+				first = _lib.OUT_SET if scratch else comb
+				launches.append(dict(term=t, target="tmp" if scratch else "out", combine=first if t_i == 0 else _lib.OUT_ADD, fold=False))
+			if scratch:
+				launches[-1]['fold'] = True          # out *= tmp after this launch
+		return launches
+
 	def _kernel_into(self, a, b, out, kwargs=None, diag_add=0.0, lower_only=False):
 		"""
 		Device-side evaluation: a (n, d), b (q, d) and out (q, n) are tensors on this process's
-		GPU.  ``diag_add`` (s^2 of gauss_procc.py:151-163) is applied with the last kernel item.
+		GPU.  ``diag_add`` (s^2 of gauss_procc.py:151-163) is applied with the last launch.
 		"""
 		lib = _lib.load()
 		items = self._resolve(dict(kwargs) if kwargs else {})
 		dt = _lib.dtype_code(out.dtype)
 		n, q = a.shape[0], b.shape[0]
-		dmax = max(len(it['group']) for it in items)
+		launches = self._plan(items)
+		dmax = max(len(l['term']['inv_ls']) for l in launches)
 		work = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, q, dmax)),), dtype=torch.uint8, device=out.device)
-		for idx, it in enumerate(items):
-			group = it['group']
-			identity = (group == list(range(a.shape[1])))
-			cols = None if identity else _dev_const(group, None, out.device, int32=True)
-			inv_ls = _dev_const(it['inv_ls'], out.dtype, out.device)
-			combine = {"-": _lib.OUT_SET, "+": _lib.OUT_ADD, "*": _lib.OUT_MUL}[it['op']]
-			last = idx == len(items) - 1
-			rc = lib.stpy_gram(it['kind'], dt, _lib.ptr(a), n, a.stride(0), _lib.ptr(b), q, b.stride(0),
-							   len(group), _lib.ptr(cols), _lib.ptr(inv_ls), it['kappa'], it['offset'],
-							   diag_add if last else 0.0, 1 if lower_only else 0, combine,
-							   _lib.ptr(out), out.stride(0), _lib.ptr(work), _lib.stream_ptr())
+		tmp = None
+		same = a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride())
+		for idx, l in enumerate(launches):
+			t = l['term']
+			last = idx == len(launches) - 1
+			if l['target'] == "tmp" and tmp is None:
+				tmp = torch.empty_like(out)
+			target = tmp if l['target'] == "tmp" else out
+			if t['premap'] is not None:
+				am = self._premap(a, t['group'], t['premap'])
+				bm = am if same else self._premap(b, t['group'], t['premap'])
+				cols, d_eff = None, am.shape[1]
+			else:
+				am, bm, d_eff = a, b, len(t['group'])
+				cols = None if t['group'] == list(range(a.shape[1])) else _dev_const(t['group'], None, out.device, int32=True)
+			inv_ls = _dev_const(t['inv_ls'], out.dtype, out.device)
+			rc = lib.stpy_gram(t['kind'], dt, _lib.ptr(am), n, am.stride(0), _lib.ptr(bm), q, bm.stride(0),
+							   d_eff, _lib.ptr(cols), _lib.ptr(inv_ls), t['kappa'], t['offset'],
+							   diag_add if (last and not l['fold']) else 0.0, 1 if lower_only else 0, l['combine'],
+							   _lib.ptr(target), target.stride(0), _lib.ptr(work), _lib.stream_ptr())
 			_lib.check(rc, "stpy_gram")
+			if l['fold']:
+				out.mul_(tmp)
+				if last and diag_add != 0.0:
+					out.diagonal().add_(diag_add)
+		return out
+
+	@staticmethod
+	def _premap(x, group, cov):
+		"""x[:, group] @ cov on the device (kernels.py:487-490) through the NT product: B = cov^T."""
+		lib = _lib.load()
+		xg = x if group == list(range(x.shape[1])) else x[:, group]
+		xg = xg.contiguous()
+		ct = cov.to(device=x.device, dtype=x.dtype).t().contiguous()
+		if ct.shape[1] != xg.shape[1]:
+			raise ValueError("full-covariance kernel: cov has %d rows for %d selected columns" % (ct.shape[1], xg.shape[1]))
+		out = torch.empty((xg.shape[0], ct.shape[0]), dtype=x.dtype, device=x.device)
+		_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(x.dtype), xg.shape[0], ct.shape[0], xg.shape[1], _lib.ptr(xg), xg.stride(0),
+									_lib.ptr(ct), ct.stride(0), _lib.ptr(out), out.stride(0), 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
 		return out
 
 	def kernel(self, a, b, **kwargs):
@@ -245,15 +349,22 @@ class KernelFunction:
 		lib = _lib.load()
 		items = self._resolve(dict(kwargs) if kwargs else {})
 		dt = _lib.dtype_code(out.dtype)
-		for it in items:
-			group = it['group']
-			identity = (group == list(range(x.shape[1])))
-			cols = None if identity else _dev_const(group, None, out.device, int32=True)
-			inv_ls = _dev_const(it['inv_ls'], out.dtype, out.device)
-			combine = {"-": _lib.OUT_SET, "+": _lib.OUT_ADD, "*": _lib.OUT_MUL}[it['op']]
-			rc = lib.stpy_gram_diag(it['kind'], dt, _lib.ptr(x), x.shape[0], x.stride(0), len(group), _lib.ptr(cols),
-									_lib.ptr(inv_ls), it['kappa'], it['offset'], combine, _lib.ptr(out), _lib.stream_ptr())
+		tmp = None
+		for l in self._plan(items):
+			t = l['term']
+			if l['target'] == "tmp" and tmp is None:
+				tmp = torch.empty_like(out)
+			target = tmp if l['target'] == "tmp" else out
+			# (a mapped stationary kernel has k(x, x) = kappa whatever the map; only dot-product kernels read x)
+			group = t['group'] if t['premap'] is None else list(range(x.shape[1]))
+			d_eff = len(group) if t['premap'] is None else 0
+			cols = None if group == list(range(x.shape[1])) else _dev_const(group, None, out.device, int32=True)
+			inv_ls = _dev_const(t['inv_ls'], out.dtype, out.device)
+			rc = lib.stpy_gram_diag(t['kind'], dt, _lib.ptr(x), x.shape[0], x.stride(0), d_eff, _lib.ptr(cols),
+									_lib.ptr(inv_ls), t['kappa'], t['offset'], l['combine'], _lib.ptr(target), _lib.stream_ptr())
 			_lib.check(rc, "stpy_gram_diag")
+			if l['fold']:
+				out.mul_(tmp)
 		return out
 
 	def kernel_self_diag(self, x, **kwargs):

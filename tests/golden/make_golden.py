@@ -314,6 +314,56 @@ def main():
 	save("H1_helpers", interval_5_2=helper.interval(5, 2), interval_4_1_half=helper.interval(4, 1, L_infinity_ball=0.5),
 		 cartesian_2x3=helper.cartesian([np.array([1., 2.]), np.array([3., 4., 5.])]))
 
+	# ---------------------------------------------------------------- K2: additive-group, full-covariance and polynomial kernels
+	# (own RNG stream so the fixtures above stay reproducible)
+	rng2 = np.random.RandomState(20241102)
+	a = rng2.uniform(-1, 1, size=(6, 5))
+	b = rng2.uniform(-1, 1, size=(9, 5))
+	x7 = rng2.uniform(-1, 1, size=(7, 5))
+	out = {}
+	groups = [[0, 1], [2], [3, 4]]
+	ag = torch.tensor([0.5, 1.0, 2.0, 0.8, 1.5], dtype=torch.float64)
+	out["ard_additive"] = N(KernelFunction(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups).kernel(T(a), T(b)))
+	gpg = [0.6, 1.1, 2.0]
+	out["se_per_group"] = N(KernelFunction(kernel_name="squared_exponential_per_group", kappa=1.3, d=5, groups=groups,
+										   params={'gamma_per_group': gpg}).kernel(T(a), T(b)))
+	apg = torch.tensor([0.5, 1.0, 2.0, 0.8, 1.5], dtype=torch.float64)
+	out["ard_per_group"] = N(KernelFunction(kernel_name="ard_per_group", kappa=1.3, d=5, groups=groups,
+											params={'ard_per_group': apg}).kernel(T(a), T(b)))
+	cov = rng2.normal(size=(5, 5)) * 0.6
+	out["cov"] = cov
+	out["fullcov_se"] = N(KernelFunction(kernel_name="full_covariance_se", cov=T(cov), kappa=1.2, d=5).kernel(T(a), T(b)))
+	cov3 = rng2.normal(size=(3, 3)) * 0.8
+	out["cov3"] = cov3
+	out["fullcov_se_group"] = N(KernelFunction(kernel_name="full_covariance_se", cov=T(cov3), kappa=1.2, d=5, group=[0, 2, 4]).kernel(T(a), T(b)))
+	for nu in (0.5, 1.5, 2.5):
+		out["fullcov_matern_%s" % str(nu).replace(".", "")] = N(KernelFunction(kernel_name="full_covariance_matern", cov=T(cov), nu=nu, kappa=0.7, d=5).kernel(T(a), T(b)))
+	for p in (1, 2, 3, 5):
+		out["poly_%d" % p] = N(KernelFunction(kernel_name="polynomial", power=p, kappa=1.4, d=5).kernel(T(a), T(b)))
+	out["poly_3_group"] = N(KernelFunction(kernel_name="polynomial", power=3, kappa=1.4, d=5, group=[1, 3]).kernel(T(a), T(b)))
+	# additive polynomial: the reference indexes the already-subset columns with `group` again
+	try:
+		KernelFunction(kernel_name="polynomial", power=2, kappa=1.0, d=5, groups=groups).kernel(T(a), T(b))
+		out["poly_additive_raises"] = np.array(0)
+	except Exception as e:                                          # noqa: BLE001
+		out["poly_additive_raises"] = np.array(1)
+	# kernel algebra on top of the new families, and the self-kernel of a multi-term item
+	k1 = KernelFunction(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups)
+	k2 = KernelFunction(kernel_name="polynomial", power=2, kappa=0.3, d=5)
+	out["sum_additive_poly"] = N((k1 + k2).kernel(T(a), T(b)))
+	k1 = KernelFunction(kernel_name="squared_exponential", gamma=0.9, kappa=1.1, d=5)
+	k2 = KernelFunction(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups)
+	out["prod_se_additive"] = N((k1 * k2).kernel(T(a), T(b)))
+	out["ard_additive_self"] = N(KernelFunction(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups).kernel(T(x7), T(x7)))
+	# a GP on an additive kernel end to end
+	x = rng2.uniform(-1, 1, size=(96, 5)); xtest = rng2.uniform(-1, 1, size=(20, 5))
+	y = np.sin(x[:, :1] + x[:, 2:3]) + 0.05 * rng2.normal(size=(96, 1))
+	GP = GaussianProcess(kernel=KernelFunction(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups), s=0.1, d=5)
+	GP.fit_gp(T(x), T(y))
+	mu, std = GP.mean_std(T(xtest))
+	save("K2_more_kernels", a=a, b=b, x7=x7, groups_flat=np.array([0, 1, -1, 2, -1, 3, 4]), p_ard_gamma=N(ag), p_gamma_per_group=np.array(gpg),
+		 p_ard_per_group=N(apg), gp_x=x, gp_y=y, gp_xtest=xtest, gp_mu=N(mu), gp_std=N(std), gp_lml=lml(GP), **out)
+
 
 if __name__ == "__main__":
 	main()

@@ -83,8 +83,81 @@ def test_K1_kernels(S):
 	assert kse.kernel(a.cuda(), b.cuda()).is_cuda
 	with pytest.raises(NotImplementedError):
 		KF(kernel_name="laplace", d=3)
+	with pytest.raises(NotImplementedError):
+		KF(kernel_name="gibbs", d=3)
 	with pytest.raises(AssertionError):
 		KF(kernel_name="no_such_kernel", d=3)
+
+
+def k2_objects(S, g):
+	"""(fixture key, drop-in KernelFunction) for every kernel of K2_more_kernels."""
+	KF = S.KernelFunction
+	groups = [[0, 1], [2], [3, 4]]
+	ag = T(g["p_ard_gamma"])
+	out = [
+		("ard_additive", KF(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups)),
+		("se_per_group", KF(kernel_name="squared_exponential_per_group", kappa=1.3, d=5, groups=groups, params={'gamma_per_group': list(g["p_gamma_per_group"])})),
+		("ard_per_group", KF(kernel_name="ard_per_group", kappa=1.3, d=5, groups=groups, params={'ard_per_group': T(g["p_ard_per_group"])})),
+		("fullcov_se", KF(kernel_name="full_covariance_se", cov=T(g["cov"]), kappa=1.2, d=5)),
+		("fullcov_se_group", KF(kernel_name="full_covariance_se", cov=T(g["cov3"]), kappa=1.2, d=5, group=[0, 2, 4])),
+		("poly_3_group", KF(kernel_name="polynomial", power=3, kappa=1.4, d=5, group=[1, 3])),
+		("sum_additive_poly", KF(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups) + KF(kernel_name="polynomial", power=2, kappa=0.3, d=5)),
+		("prod_se_additive", KF(kernel_name="squared_exponential", gamma=0.9, kappa=1.1, d=5) * KF(kernel_name="ard", ard_gamma=ag, kappa=0.9, d=5, groups=groups)),
+	]
+	for nu in (0.5, 1.5, 2.5):
+		out.append(("fullcov_matern_" + str(nu).replace(".", ""), KF(kernel_name="full_covariance_matern", cov=T(g["cov"]), nu=nu, kappa=0.7, d=5)))
+	for p in (1, 2, 3, 5):
+		out.append(("poly_%d" % p, KF(kernel_name="polynomial", power=p, kappa=1.4, d=5)))
+	return out
+
+
+def test_K2_more_kernels(S):
+	"""Additive-group SE/ARD, full-covariance SE/Matern and polynomial kernels (kernels.py:464-549, :620-761)
+	against the reference's outputs, and at a ragged multi-tile size against the oracle."""
+	from tests.test_oracle_golden import k2_specs
+	g = golden("K2_more_kernels")
+	a, b = T(g["a"]), T(g["b"])
+	objs = k2_objects(S, g)
+	for key, k in objs:
+		out = k.kernel(a, b)
+		assert tuple(out.shape) == (9, 6)
+		assert rel_err(N(out), g[key]) < 1e-13, key
+	KF = S.KernelFunction
+	kadd = KF(kernel_name="ard", ard_gamma=T(g["p_ard_gamma"]), kappa=0.9, d=5, groups=[[0, 1], [2], [3, 4]])
+	ks = N(kadd.kernel(T(g["x7"]), T(g["x7"])))
+	assert rel_err(ks, g["ard_additive_self"]) < 1e-13
+	assert rel_err(N(kadd.kernel_self_diag(T(g["x7"]))), np.diag(g["ard_additive_self"])) < 1e-13
+	with pytest.raises(NotImplementedError):
+		KF(kernel_name="polynomial", power=2, d=5, groups=[[0, 1], [2], [3, 4]])
+	with pytest.raises(AssertionError):
+		KF(kernel_name="squared_exponential_per_group", d=5, groups=[[0, 1], [2], [3, 4]]).kernel(a, b)
+	# multi-tile, ragged sizes on the device against the oracle (same specs the CPU suite pins to the reference)
+	rng = np.random.RandomState(77)
+	A, B = rng.uniform(-1, 1, size=(300, 5)), rng.uniform(-1, 1, size=(203, 5))
+	specs = dict(k2_specs(g))
+	for key, k in k2_objects(S, g):
+		out = k.kernel(T(A, True), T(B, True))
+		assert out.is_cuda
+		assert rel_err(N(out), O.kernel(A, B, specs[key])) < 1e-12, key
+		# self-kernel diagonal entry point agrees with the full matrix
+		full = N(k.kernel(T(A, True), T(A, True)))
+		assert rel_err(N(k.kernel_self_diag(T(A, True))), np.diag(full)) < 1e-12, key
+	# GP end to end on the additive kernel
+	GP = S.GaussianProcess(kernel=KF(kernel_name="ard", ard_gamma=T(g["p_ard_gamma"]), kappa=0.9, d=5, groups=[[0, 1], [2], [3, 4]]), s=0.1, d=5)
+	GP.fit_gp(T(g["gp_x"]), T(g["gp_y"]))
+	mu, std = GP.mean_std(T(g["gp_xtest"]))
+	assert rel_err(N(mu), g["gp_mu"]) < TOL and rel_err(N(std), g["gp_std"]) < TOL
+	assert abs(lml(GP) - g["gp_lml"].item()) / abs(g["gp_lml"].item()) < TOL
+	# a product with a multi-term item on the training Gram (scratch-buffer path + s^2 on the diagonal)
+	kprod = KF(kernel_name="squared_exponential", gamma=0.9, kappa=1.1, d=5) * KF(kernel_name="ard", ard_gamma=T(g["p_ard_gamma"]), kappa=0.9, d=5, groups=[[0, 1], [2], [3, 4]])
+	GP2 = S.GaussianProcess(kernel=kprod, s=0.3, d=5)
+	GP2.fit_gp(T(g["gp_x"]), T(g["gp_y"]))
+	Kref = O.kernel(g["gp_x"], g["gp_x"], specs["prod_se_additive"]) + 0.09 * np.eye(96)
+	assert rel_err(N(GP2.get_kernel()), Kref) < 1e-12
+	Lo, alo = O.fit(g["gp_x"], g["gp_y"], specs["prod_se_additive"], 0.3)
+	muo, stdo = O.mean_std(g["gp_x"], Lo, alo, g["gp_xtest"], specs["prod_se_additive"])
+	mu2, std2 = GP2.mean_std(T(g["gp_xtest"]))
+	assert rel_err(N(mu2), muo) < TOL and rel_err(N(std2), stdo) < TOL
 
 
 @pytest.mark.parametrize("name,tol", [("G1_c1_s001", 2e-6), ("G1_c1_s01", TOL)])

@@ -54,6 +54,47 @@ def test_K1_kernels():
 	assert np.abs(g["se_self"] - g["se_self"].T).max() < 1e-15
 
 
+K2_GROUPS = [[0, 1], [2], [3, 4]]
+
+
+def k2_specs(g):
+	"""(fixture key, oracle spec) for every kernel of K2_more_kernels -- shared with the GPU tests."""
+	ag = g["p_ard_gamma"]
+	out = [
+		("ard_additive", [("ard_additive", {"ard_gamma": ag, "groups": K2_GROUPS, "kappa": 0.9}, "-")]),
+		("se_per_group", [("squared_exponential_per_group", {"groups": K2_GROUPS, "gamma_per_group": g["p_gamma_per_group"], "kappa": 1.3}, "-")]),
+		("ard_per_group", [("ard_per_group", {"groups": K2_GROUPS, "ard_per_group": g["p_ard_per_group"], "kappa": 1.3}, "-")]),
+		("fullcov_se", [("full_covariance_se", {"cov": g["cov"], "kappa": 1.2}, "-")]),
+		("fullcov_se_group", [("full_covariance_se", {"cov": g["cov3"], "kappa": 1.2, "group": [0, 2, 4]}, "-")]),
+		("poly_3_group", [("polynomial", {"degree": 3, "kappa": 1.4, "group": [1, 3]}, "-")]),
+		("sum_additive_poly", [("ard_additive", {"ard_gamma": ag, "groups": K2_GROUPS, "kappa": 0.9}, "-"),
+							   ("polynomial", {"degree": 2, "kappa": 0.3}, "+")]),
+		("prod_se_additive", [("squared_exponential", {"gamma": 0.9, "kappa": 1.1}, "-"),
+							  ("ard_additive", {"ard_gamma": ag, "groups": K2_GROUPS, "kappa": 0.9}, "*")]),
+	]
+	for nu in (0.5, 1.5, 2.5):
+		out.append(("fullcov_matern_" + str(nu).replace(".", ""), [("full_covariance_matern", {"cov": g["cov"], "nu": nu, "kappa": 0.7}, "-")]))
+	for p in (1, 2, 3, 5):
+		out.append(("poly_%d" % p, [("polynomial", {"degree": p, "kappa": 1.4}, "-")]))
+	return out
+
+
+def test_K2_more_kernels():
+	g = golden("K2_more_kernels")
+	a, b = g["a"], g["b"]
+	for key, spec in k2_specs(g):
+		assert g[key].shape == (9, 6)
+		assert rel_err(O.kernel(a, b, spec), g[key]) < 1e-14, key
+	spec = [("ard_additive", {"ard_gamma": g["p_ard_gamma"], "groups": K2_GROUPS, "kappa": 0.9}, "-")]
+	assert rel_err(O.kernel(g["x7"], g["x7"], spec), g["ard_additive_self"]) < 1e-14
+	assert int(g["poly_additive_raises"]) == 1        # the reference's own additive-polynomial path fails (double column subset)
+	# GP on the additive kernel, end to end
+	L, alpha = O.fit(g["gp_x"], g["gp_y"], spec, 0.1)
+	mu, std = O.mean_std(g["gp_x"], L, alpha, g["gp_xtest"], spec)
+	assert rel_err(mu, g["gp_mu"]) < TOL and rel_err(std, g["gp_std"]) < TOL
+	assert abs(O.log_marginal(g["gp_x"], g["gp_y"], spec, 0.1) - g["gp_lml"].item()) / abs(g["gp_lml"].item()) < TOL
+
+
 @pytest.mark.parametrize("name,tol", [("G1_c1_s001", TOL_ILL), ("G1_c1_s01", 1e-8)])
 def test_G1_config1(name, tol):
 	g = golden(name)
