@@ -18,7 +18,9 @@
  *   - return value: 0 = ok, <0 = invalid argument (-(index of the argument), 1-based) or
  *     -1000-hipError for a failed launch; numerical failure of the factorisation is reported
  *     through the device word `info_dev` (0 = ok, j>0 = leading minor j not positive definite),
- *     exactly LAPACK's potrf convention, so the host decides when to synchronise and read it.
+ *     exactly LAPACK's potrf convention, so the host decides when to synchronise and read it;
+ *   - an empty problem (an output with a zero dimension: no test points, no rows) returns 0 without
+ *     looking at any pointer -- empty tensors have null data pointers.
  */
 #ifndef STPY_HIP_H
 #define STPY_HIP_H

@@ -75,6 +75,7 @@ int stpy_gram(int kind, int dtype, const void* a, int64_t n, int64_t lda, const 
               int d, const int32_t* cols, const void* inv_ls, double kappa, double offset, double diag_add,
               int lower_only, int combine, void* out, int64_t ldo, void* work, void* stream)
 {
+	if (n <= 0 || q <= 0) return 0;          // empty problem: nothing to write (empty tensors have null data pointers)
 	if (!a || !b || !out || !inv_ls) { set_error("stpy_gram: null pointer"); return -3; }
 	if (d <= 0 || lda < 1 || ldb < 1 || ldo < n) { set_error("stpy_gram: bad dimensions d=%d ldo=%lld n=%lld", d, (long long)ldo, (long long)n); return -9; }
 	hipStream_t st = (hipStream_t)stream;
@@ -91,6 +92,7 @@ int64_t stpy_gram_workspace_bytes(int dtype, int64_t n, int64_t q, int d)
 int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
                    double kappa, double offset, int combine, void* out, void* stream)
 {
+	if (m <= 0) return 0;
 	if (!x || !out || !inv_ls) { set_error("stpy_gram_diag: null pointer"); return -3; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
@@ -118,6 +120,7 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* wor
 
 int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* stream)
 {
+	if (m <= 0 || n <= 0) return 0;
 	if (!L || !winv || !B) { set_error("stpy_trsm_right_lt: null pointer"); return -4; }
 	if (m < 0 || n <= 0 || ldl < n || ldb < n) { set_error("stpy_trsm_right_lt: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
@@ -159,6 +162,7 @@ int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv
 int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, const void* z, const void* kdiag,
                  void* mu, void* sigma, int clamp, void* stream)
 {
+	if (m <= 0) return 0;
 	if (!X || !z || (sigma && !kdiag && clamp != 2)) { set_error("stpy_predict: null pointer"); return -4; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
@@ -178,6 +182,7 @@ int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const voi
 int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
                  void* C, int64_t ldc, int mode, int lower_only, void* stream)
 {
+	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt: null pointer"); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	ProfScope ps(TAG_GEMM_API, (lower_only && m == n) ? (double)m * (double)n * (double)k : 2.0 * (double)m * (double)n * (double)k, st);
@@ -194,6 +199,7 @@ int stpy_gemm_nt_splitk_passes(int64_t m, int64_t n, int64_t k)
 int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
                         void* C, int64_t ldc, int mode, int passes, void* work, void* stream)
 {
+	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt_splitk: null pointer"); return -5; }
 	if (passes > 1 && !work) { set_error("stpy_gemm_nt_splitk: %d passes need a workspace of passes*m*n elements", passes); return -5; }
 	if (mode != 0 && mode != 1) { set_error("stpy_gemm_nt_splitk: mode must be 0 or 1"); return -11; }
@@ -207,6 +213,7 @@ int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k, const void* 
 int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
                     void* C, int64_t ldc, int mode, int nb_dist, int pr, int pc, int myr, int myc, int i0, int j0, void* stream)
 {
+	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt_bc: null pointer"); return -5; }
 	if (pr <= 0 || pc <= 0 || myr < 0 || myr >= pr || myc < 0 || myc >= pc || i0 < 0 || j0 < 0) { set_error("stpy_gemm_nt_bc: bad process-grid arguments"); return -13; }
 	hipStream_t st = (hipStream_t)stream;
@@ -227,6 +234,7 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, const void* W, int64_t ldw, int64_t m,
                    const void* bias, double scale, void* out, int64_t ldo, int transposed, void* stream)
 {
+	if (n <= 0 || m <= 0) return 0;
 	if (!x || !W || !out) { set_error("stpy_rff_embed: null pointer"); return -2; }
 	if (d <= 0 || ldx < d || ldw < d || ldo < (transposed ? n : m)) { set_error("stpy_rff_embed: bad dimensions"); return -5; }
 	hipStream_t st = (hipStream_t)stream;

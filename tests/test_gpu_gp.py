@@ -489,6 +489,49 @@ def test_G12_kernelized_features(S):
 		KernelizedFeatures(embedding=emb, m=m, primal=False)
 
 
+def test_edge_cases_closed_forms(S):
+	"""Anchors the reference's tests lack: N = 1 closed forms, one test point,
+	sizes around the 128 tile edge, coincident training points, an empty test set."""
+	kappa, s, gamma = 1.7, 0.3, 0.8
+	GP = S.GaussianProcess(gamma=gamma, s=s, kappa=kappa, kernel_name="squared_exponential", d=2)
+	x1 = torch.tensor([[0.2, -0.4]], dtype=torch.float64)
+	y1 = torch.tensor([[1.3]], dtype=torch.float64)
+	GP.fit_gp(x1, y1)
+	xt = torch.tensor([[0.2, -0.4], [0.5, 0.1]], dtype=torch.float64)
+	mu, std = GP.mean_std(xt)
+	kstar = kappa * np.exp(-0.5 * np.array([0.0, 0.3 ** 2 + 0.5 ** 2]) / gamma ** 2)
+	assert np.allclose(N(mu).ravel(), kstar * 1.3 / (kappa + s * s), rtol=1e-13)
+	assert np.allclose(N(std).ravel(), np.sqrt(kappa - kstar ** 2 / (kappa + s * s)), rtol=1e-13)
+	assert abs(lml(GP) - (0.5 * 1.3 ** 2 / (kappa + s * s) + 0.5 * np.log(kappa + s * s))) < 1e-13
+	# one test point; empty test set
+	mu1, std1 = GP.mean_std(xt[:1])
+	assert tuple(mu1.shape) == (1, 1) and tuple(std1.shape) == (1, 1)
+	mu0, std0 = GP.mean_std(xt[:0])
+	assert tuple(mu0.shape) == (0, 1) and tuple(std0.shape) == (0, 1)
+	# sizes around the tile edge, with two coincident training points (K is singular without the noise term)
+	rng = np.random.RandomState(3)
+	for n in (2, 127, 128, 129, 257):
+		x = rng.uniform(-1, 1, size=(n, 2))
+		x[-1] = x[0]
+		y = np.sin(x.sum(axis=1, keepdims=True))
+		xq = rng.uniform(-1, 1, size=(5, 2))
+		spec = [("squared_exponential", {"gamma": gamma, "kappa": kappa}, "-")]
+		GP = S.GaussianProcess(gamma=gamma, s=s, kappa=kappa, kernel_name="squared_exponential", d=2)
+		GP.fit_gp(T(x), T(y))
+		mu, std = GP.mean_std(T(xq))
+		L, alpha = O.fit(x, y, spec, s)
+		muo, stdo = O.mean_std(x, L, alpha, xq, spec)
+		assert rel_err(N(mu), muo) < TOL and rel_err(N(std), stdo) < TOL, n
+		assert abs(lml(GP) - O.log_marginal(x, y, spec, s)) / abs(O.log_marginal(x, y, spec, s)) < TOL, n
+	# interpolation limit: s -> 0 reproduces the training targets
+	x = rng.uniform(-1, 1, size=(40, 2))
+	y = np.sin(x.sum(axis=1, keepdims=True))
+	GP = S.GaussianProcess(gamma=0.5, s=1e-6, kappa=1.0, kernel_name="squared_exponential", d=2)
+	GP.fit_gp(T(x), T(y))
+	mu, std = GP.mean_std(T(x))
+	assert np.abs(N(mu) - y).max() < 1e-6 and N(std).max() < 1e-4
+
+
 def test_not_positive_definite_raises(S):
 	x = torch.zeros((300, 2), dtype=torch.float64)        # 300 identical points, no noise -> singular
 	GP = S.GaussianProcess(gamma=1.0, s=0.0, kappa=1.0, kernel_name="squared_exponential", d=2)
