@@ -32,7 +32,8 @@ SIGNATURES = {
 	"stpy_potrf_workspace_bytes": (_i64, [_i32, _i64, _i32]),
 	"stpy_potrf_winv_elems": (_i64, [_i64]),
 	"stpy_potrf": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
-	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp]),
+	"stpy_trsm_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32]),
+	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp]),
 	"stpy_potri": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
 	"stpy_lml_weight": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp]),
 	"stpy_trsv": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),

@@ -299,8 +299,9 @@ class GaussianProcess:
 		st = _lib.stream_ptr
 		X = torch.empty((m, n), dtype=xd.dtype, device=xd.device)
 		ko._kernel_into(xd, xt, X)                                      # K* = k(x, xtest): (M, N)   :346
+		tw = torch.empty((int(lib.stpy_trsm_workspace_bytes(dt, m, n, self.nb)),), dtype=torch.uint8, device=X.device)
 		_lib.check(lib.stpy_trsm_right_lt(dt, m, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv),
-										  _lib.ptr(X), X.stride(0), self.nb, st()), "stpy_trsm_right_lt")   # X = K* L^-T
+										  _lib.ptr(X), X.stride(0), self.nb, _lib.ptr(tw), st()), "stpy_trsm_right_lt")   # X = K* L^-T
 		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
 		if not full:
 			kd = torch.empty((m,), dtype=xd.dtype, device=xd.device)

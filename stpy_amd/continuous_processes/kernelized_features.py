@@ -195,7 +195,7 @@ class KernelizedFeatures:
 		M, m = X.shape
 		dt = _lib.dtype_code(L.dtype)
 		st = _lib.stream_ptr
-		_lib.check(lib.stpy_trsm_right_lt(dt, M, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), _lib.ptr(X), X.stride(0), self.nb, st()), "stpy_trsm_right_lt")
+		_lib.check(lib.stpy_trsm_right_lt(dt, M, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), _lib.ptr(X), X.stride(0), self.nb, None, st()), "stpy_trsm_right_lt")
 		mu, ss = torch.empty((M,), dtype=L.dtype, device=L.device), torch.empty((M,), dtype=L.dtype, device=L.device)
 		_lib.check(lib.stpy_predict(dt, M, m, _lib.ptr(X), X.stride(0), _lib.ptr(self._u), None, _lib.ptr(mu), _lib.ptr(ss), 2, st()), "stpy_predict")
 		std = float(self.s) * torch.sqrt(ss)

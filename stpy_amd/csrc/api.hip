@@ -118,15 +118,23 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* wor
 	         potrf<float>(n, (float*)A, lda, (float*)winv, (float*)work, nb, info_dev, st));
 }
 
-int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* stream)
+int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
+{
+	if (m <= 0 || n <= 0) return 0;
+	if (nb <= 0) nb = trsm_auto_nb(m);
+	if (n <= nb) return 0;
+	return (int64_t)TRSM_MAX_PASSES * m * nb * (int64_t)(dtype == STPY_F32 ? 4 : 8);
+}
+
+int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* work, void* stream)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!L || !winv || !B) { set_error("stpy_trsm_right_lt: null pointer"); return -4; }
 	if (m < 0 || n <= 0 || ldl < n || ldb < n) { set_error("stpy_trsm_right_lt: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         trsm_right_lt<double>(m, n, (const double*)L, ldl, (const double*)winv, (double*)B, ldb, nb, st),
-	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st));
+	         trsm_right_lt<double>(m, n, (const double*)L, ldl, (const double*)winv, (double*)B, ldb, nb, st, false, (double*)work),
+	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st, false, (float*)work));
 }
 
 int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* Kinv, int64_t ldk, void* work, void* stream)
@@ -249,6 +257,9 @@ void stpy_tune(int key, int value)
 	if (key == 0) g_gemm_stagger = value;
 	if (key == 1) g_gemm_exp = value;
 	if (key == 2) g_potf2_scalar = value;
+	if (key == 3) g_trsm_pass_depth = value > 0 ? value : 1024;
+	if (key == 4) g_trsm_wg_target = value > 0 ? value : 2048;
+	if (key == 5) g_trsm_right_looking = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */

@@ -72,7 +72,10 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 template <typename T>
 int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st);
 template <typename T>
-int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false);
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false, T* work = nullptr);
+int trsm_auto_nb(int64_t m);
+constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
+extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
 template <typename T>

@@ -38,11 +38,11 @@ static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, 
 
 #define HIPCHK_S(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("trsm: %s failed: %s", #x, hipGetErrorString(e_)); return -1000 - (int)e_; } } while (0)
 
-// Right-looking between panels with one panel of look-ahead (same scheme as potrf): after panel k is
+// Without a workspace (and for A/B timing under stpy_tune key 5): right-looking between panels with one panel of look-ahead (same scheme as potrf): after panel k is
 // solved, the update of the NEXT panel's columns goes first, then the next panel's latency-bound
 // 128-blocks run on the side stream while the caller's stream updates the remaining columns.
 template <typename T>
-int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs)
+static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs)
 {
 	if (nb <= 0) nb = TRSM_DEFAULT_NB;
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
@@ -73,6 +73,82 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 		}
 		HIPCHK_S(hipStreamWaitEvent(st, la->panel_done, 0));
 	}
+	return 0;
+}
+
+
+// LEFT-looking between panels: panel p (columns [k, k+nb)) first receives every earlier panel's
+// contribution in ONE long-K product,  B[:, k:k+nb] -= X[:, 0:k) L[k:k+nb, 0:k)^T,  and is then solved.
+// The output of that product is read and written once per panel (a right-looking sweep re-reads
+// the whole remaining right-hand side once per panel, at K = nb per visit), and a long K range
+// amortises the per-tile prologue/epilogue (70 TFLOP/s fp64 on these shapes in isolation,
+// tools/quick_bench.py leftlook).  In place the whole solve gains less: 299 ms against 311 ms for the
+// right-looking sweep at N = 65536, M = 4096 (tools/predict_bench.py) -- 59 vs 57 TFLOP/s.
+// Look-ahead: the product is split at the previous panel.  G1(p+1), the part over columns [0, k) that
+// needs only panels <= p-1, runs on the caller's stream while the side stream finishes panel p:
+// G2(p) (the K = nb slice over panel p-1) and the latency-bound 128-blocks S(p).
+// G1 is cut into K passes (workspace) so that it runs as several rounds of workgroups and the side
+// stream's kernels get CU slots in between.
+int g_trsm_right_looking = 0;
+int g_trsm_pass_depth = 1024;     // least K depth of one pass
+int g_trsm_wg_target = 2048;      // workgroups a long product is cut into (four rounds of two per CU)
+
+int trsm_auto_nb(int64_t)
+{
+	return TRSM_DEFAULT_NB;
+}
+
+template <typename T>
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs, T* work)
+{
+	// no workspace: the long products cannot be cut into K passes, and one round of workgroups that
+	// holds every CU slot would keep the next panel's small kernels out -- the right-looking sweep
+	// is the faster form then (311 vs 335 ms at N = 65536, M = 4096; 299 ms with the workspace)
+	if (g_trsm_right_looking || !work) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs);
+	if (nb <= 0) nb = trsm_auto_nb(m);
+	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
+	int rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs);
+	if (rc || n <= nb) return rc;
+	rc = lookahead_init();
+	if (rc) return rc;
+	LookAhead* la = lookahead_state();
+	hipStream_t side = la->side;
+	HIPCHK_S(hipEventRecord(la->col_ready, st));            // "G1(1)" is empty: panel 1 only waits for S(0)
+	for (int64_t k = nb; k < n; k += nb) {
+		const int64_t w = (n - k < nb) ? (n - k) : nb;
+		const int64_t mr = upper_rhs ? ((k < m) ? k : m) : m;   // X[:, 0:k) is zero from row k on
+		// ---- side stream: G2(p) over panel p-1, then the 128-blocks of panel p
+		HIPCHK_S(hipStreamWaitEvent(side, la->col_ready, 0));   // G1(p) (issued one iteration ago) has landed
+		{
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)w * (double)nb, side);
+			rc = gemm_nt<T>(mr, w, nb, B + (k - nb), ldb, L + k * ldl + (k - nb), ldl, B + k, ldb, (T*)nullptr, 0, 1, 0, side);
+			if (rc) return rc;
+		}
+		rc = solve_panel<T>(m, n, k, w, L, ldl, winv, B, ldb, side, upper_rhs);
+		if (rc) return rc;
+		// ---- caller's stream: G1(p+1) over columns [0, k): needs S(p-1), not S(p)
+		if (k > nb) HIPCHK_S(hipStreamWaitEvent(st, la->panel_done, 0));
+		const int64_t k1 = k + nb;
+		if (k1 < n) {
+			const int64_t w1 = (n - k1 < nb) ? (n - k1) : nb;
+			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)w1 * (double)k, st);
+			// K passes (workspace given): several rounds of shorter workgroups instead of one round that
+			// holds every CU slot for the whole product -- the side stream's kernels get in between rounds
+			int passes = 1;
+			if (work) {
+				const int64_t tiles = ((mr + IB - 1) / IB) * ((w1 + IB - 1) / IB);
+				passes = (int)(k / g_trsm_pass_depth);
+				if (passes > g_trsm_wg_target / tiles) passes = (int)(g_trsm_wg_target / tiles);
+				if (passes > TRSM_MAX_PASSES) passes = TRSM_MAX_PASSES;
+				if (passes < 1) passes = 1;
+			}
+			rc = gemm_nt<T>(mr, w1, k, B, ldb, L + k1 * ldl, ldl, B + k1, ldb, (T*)nullptr, 0, 1, 0, st, nullptr, nullptr, nullptr, passes, work);
+			if (rc) return rc;
+			HIPCHK_S(hipEventRecord(la->col_ready, st));
+		}
+		HIPCHK_S(hipEventRecord(la->panel_done, side));       // S(p); recorded AFTER the wait above, which refers to S(p-1)
+	}
+	HIPCHK_S(hipStreamWaitEvent(st, la->panel_done, 0));
 	return 0;
 }
 
@@ -321,7 +397,7 @@ int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st)
 }
 
 #define INST(T) \
-	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t, bool); \
+	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t, bool, T*); \
 	template int potri_lower<T>(int64_t, const T*, int64_t, const T*, T*, int64_t, T*, hipStream_t); \
 	template int trsv<T>(int64_t, const T*, int64_t, const T*, T*, T*, int, hipStream_t); \
 	template int predict<T>(int64_t, int64_t, const T*, int64_t, const T*, const T*, T*, T*, int, hipStream_t); \

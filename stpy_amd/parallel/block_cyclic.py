@@ -109,7 +109,7 @@ class HipLocalOps:
 		if m == 0:
 			return
 		_lib.check(self.lib.stpy_trsm_right_lt(self.code, m, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(B), B.stride(0),
-											   self.nb, _lib.stream_ptr()), "stpy_trsm_right_lt")
+											   self.nb, None, _lib.stream_ptr()), "stpy_trsm_right_lt")
 
 	def gemm_nt(self, A, B, C, mode, bc=None):
 		"""C (mode 0: =, 1: -=) A B^T.  bc = (nb_dist, pr, pc, myr, myc, i0, j0) enables the staircase."""

@@ -282,7 +282,7 @@ def test_potrf_not_positive_definite(L):
 	assert info == 171          # LAPACK convention: order of the failing leading minor
 
 
-@pytest.mark.parametrize("n,m,nb", [(128, 5, 0), (200, 130, 128), (1000, 77, 256), (1536, 256, 512), (2049, 300, 512)])
+@pytest.mark.parametrize("n,m,nb", [(128, 5, 0), (200, 130, 128), (1000, 77, 256), (1536, 256, 512), (2049, 300, 512), (6400, 200, 1024), (5000, 129, 0)])
 def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	rng = np.random.RandomState(n + m)
 	K = spd(rng, n)
@@ -292,9 +292,16 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	lib = L.load()
 	B = rng.normal(size=(m, n))
 	Bd = dev(B)
-	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, nb, L.stream_ptr()), "trsm")
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, nb, None, L.stream_ptr()), "trsm")
 	Xref = sla.solve_triangular(Lref, B.T, lower=True).T
 	assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
+	# the same solve with the K-pass workspace
+	wb = int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, nb))
+	assert (wb == 0) == (n <= (nb if nb > 0 else 512))
+	Bw = dev(B)
+	wk = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda:0")
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), L.stream_ptr()), "trsm")
+	assert rel_err(Bw.cpu().numpy(), Xref) < 1e-11
 	y = rng.normal(size=n)
 	yd, zd, ad = dev(y), torch.empty(n, dtype=torch.float64, device="cuda:0"), torch.empty(n, dtype=torch.float64, device="cuda:0")
 	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")

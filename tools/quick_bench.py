@@ -134,8 +134,34 @@ def rect():
 		del A, B, C
 
 
+def leftlook():
+	"""the shapes a LEFT-looking factorisation / solve would give: few column tiles, long K"""
+	for m, n, k, lda in ((57344, 1024, 8192, 65536), (32768, 1024, 32768, 65536), (16384, 1024, 49152, 65536), (8192, 1024, 57344, 65536),
+						 (4096, 1024, 61440, 65536), (4096, 1024, 32768, 65536), (4096, 512, 32768, 65536), (32768, 512, 32768, 65536),
+						 (32768, 2048, 32768, 65536)):
+		A = torch.randn(m, lda, dtype=torch.float64, device=dev)
+		B = torch.randn(n, lda, dtype=torch.float64, device=dev)
+		C = torch.randn(m, n, dtype=torch.float64, device=dev)
+		f = lambda: L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(A), lda, L.ptr(B), lda, L.ptr(C), n, 1, 0, L.stream_ptr()), "gemm")
+		t = timeit(f, reps=3, warm=1)[0]
+		msg = "left m=%d n=%d k=%d: plain %.3f ms %.1f TF" % (m, n, k, t * 1e3, 2.0 * m * n * k / t / 1e12)
+		tiles = (m // 128) * (n // 128)
+		for passes in (2, 4):
+			if tiles * passes > 1024 or tiles >= 512:
+				continue
+			W = torch.empty(passes * m * n, dtype=torch.float64, device=dev)
+			f2 = lambda: L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(A), lda, L.ptr(B), lda, L.ptr(C), n, 1, passes, L.ptr(W), L.stream_ptr()), "gemm")
+			t2 = timeit(f2, reps=3, warm=1)[0]
+			msg += " | %d passes %.3f ms %.1f TF" % (passes, t2 * 1e3, 2.0 * m * n * k / t2 / 1e12)
+			del W
+		print(msg, flush=True)
+		del A, B, C
+
+
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "leftlook":
+		leftlook()
 	if which == "rect":
 		rect()
 	if which == "smallk":
