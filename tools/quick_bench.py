@@ -1,4 +1,5 @@
 """Scratch micro-benchmarks of the C-ABI entry points (GPU box only)."""
+import collections
 import sys
 import time
 
@@ -79,10 +80,12 @@ def exp_gemm():
 	P = torch.randn(n, k, dtype=torch.float64, device=dev)
 	C = torch.randn(n, n, dtype=torch.float64, device=dev)
 	f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, 1, 1, L.stream_ptr()), "gemm")
-	names = {0: "baseline", 1: "no global loads after tile 0", 3: "no loads, no LDS stores", 7: "no loads/stores/barrier", 15: "same + no buffer flip",
-			 16: "no L2 warm-up touch", 2: "loads kept, no LDS stores", 6: "loads kept, no stores, no barrier", 4: "no barrier only (racy)"}
+	names = collections.defaultdict(str)
+	names.update({5: "no loads after tile 0, no barrier", 8: "no buffer flip (reads one LDS buffer)", 13: "no loads, no barrier, no flip"})
+	names.update({0: "baseline", 1: "no global loads after tile 0", 3: "no loads, no LDS stores", 7: "no loads/stores/barrier", 15: "same + no buffer flip",
+			 2: "loads kept, no LDS stores", 6: "loads kept, no stores, no barrier", 4: "no barrier only (racy)"})
 	for rnd in range(2):
-		for e in (0, 16, 1, 4):
+		for e in (0, 1, 4, 5):
 			lib.stpy_tune(1, e)
 			t = timeit(f, reps=2, warm=1)[0]
 			print("exp=%2d %-36s %.3f ms  %.1f TF" % (e, names[e], t * 1e3, float(n) * n * k / t / 1e12), flush=True)
@@ -120,6 +123,25 @@ def small_k():
 			f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, mode, 1, L.stream_ptr()), "gemm")
 			t = timeit(f, reps=3, warm=1)[0]
 			print("n=%d k=%4d mode=%d: %.3f ms  (%.2f us per round of 512 tiles)  C-bytes/time = %.2f TB/s" % (n, k, mode, t * 1e3, t * 1e6 / (32896 / 512.0), (2 if mode else 1) * n * n * 4 / t / 1e12), flush=True)
+
+
+def fixed_cost():
+	"""t(k) per round of 512 tiles for the trailing-update shape: separates the per-tile fixed cost from the K slope"""
+	n = 32768
+	C = torch.randn(n, n, dtype=torch.float64, device=dev)
+	rounds = (n // 128) * (n // 128 + 1) / 2 / 512.0
+	for mode in (1, 0):
+		pts = []
+		for k in (256, 512, 1024, 2048, 4096):
+			P = torch.randn(n, k, dtype=torch.float64, device=dev)
+			f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, mode, 1, L.stream_ptr()), "gemm")
+			t = timeit(f, reps=3, warm=1)[0]
+			pts.append((k, t * 1e6 / rounds))
+			print("mode=%d k=%4d: %.3f ms  %.1f us/round  %.1f TF" % (mode, k, t * 1e3, t * 1e6 / rounds, float(n) * (n + 128) * k / t / 1e12), flush=True)
+			del P
+		(k0, t0), (k1, t1) = pts[2], pts[4]
+		b = (t1 - t0) / (k1 - k0)
+		print("mode=%d: slope %.4f us per k per round (= %.1f TF), fixed %.1f us per round" % (mode, b, 512 * 2.0 * 128 * 128 / b / 1e6, t0 - b * k0), flush=True)
 
 
 def rect():
@@ -160,6 +182,8 @@ def leftlook():
 
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "fixed":
+		fixed_cost()
 	if which == "leftlook":
 		leftlook()
 	if which == "rect":
@@ -182,4 +206,5 @@ if __name__ == "__main__":
 		for n, nb in ((8192, 512), (16384, 512), (32768, 512), (32768, 256), (32768, 1024)):
 			bench_potrf(n, nb)
 	if which == "big":
-		bench_potrf(65536, 512)
+		for nb in (1024, 1536, 2048, 3072, 1024):
+			bench_potrf(65536, nb)
