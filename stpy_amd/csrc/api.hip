@@ -102,7 +102,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, i
 
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
 {
-	if (nb <= 0) nb = POTRF_DEFAULT_NB;
+	if (nb <= 0) nb = potrf_auto_nb(n);
 	return 2 * n * (int64_t)nb * (dtype == STPY_F64 ? 8 : 4);     /* two panel workspaces (look-ahead) */
 }
 
@@ -122,7 +122,7 @@ int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (nb <= 0) nb = trsm_auto_nb(m);
-	if (n <= nb) return 0;
+	if (n <= nb || (n < 32768 && g_trsm_right_looking != 2)) return 0;       // the right-looking sweep serves these sizes and needs none
 	return (int64_t)TRSM_MAX_PASSES * m * nb * (int64_t)(dtype == STPY_F32 ? 4 : 8);
 }
 

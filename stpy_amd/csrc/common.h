@@ -10,6 +10,9 @@ namespace stpy {
 
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
+// panel width when the caller passes nb = 0: narrower panels shorten the latency-bound panel chain, which a
+// small trailing matrix cannot hide (measured, tools/phase_bench.py: N = 8k / 16k: 256; 32k: 512; 64k: 1024)
+inline int potrf_auto_nb(int64_t n) { return n <= 16384 ? 256 : (n <= 32768 ? 512 : POTRF_DEFAULT_NB); }
 
 extern int g_gemm_stagger;
 extern int g_gemm_exp;

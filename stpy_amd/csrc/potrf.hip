@@ -422,7 +422,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 template <typename T>
 int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st)
 {
-	if (nb <= 0) nb = POTRF_DEFAULT_NB;
+	if (nb <= 0) nb = potrf_auto_nb(n);
 	if (nb % IB != 0) { set_error("potrf: nb must be a multiple of %d", IB); return -7; }
 	HIPCHK(hipMemsetAsync(info, 0, sizeof(int32_t), st));
 	const int64_t ldp = nb;

@@ -104,7 +104,9 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 	// no workspace: the long products cannot be cut into K passes, and one round of workgroups that
 	// holds every CU slot would keep the next panel's small kernels out -- the right-looking sweep
 	// is the faster form then (311 vs 335 ms at N = 65536, M = 4096; 299 ms with the workspace)
-	if (g_trsm_right_looking || !work) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs);
+	// ... and below n = 32768 in any case (28.1 vs 29.9 ms at n = 16384, 10.0 vs 11.0 at 8192, equal at 32768)
+	// (stpy_tune key 5: 1 forces the right-looking sweep, 2 the left-looking form at any n -- tests, A/B timing)
+	if (g_trsm_right_looking == 1 || !work || (n < 32768 && g_trsm_right_looking != 2)) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs);
 	if (nb <= 0) nb = trsm_auto_nb(m);
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
 	int rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs);

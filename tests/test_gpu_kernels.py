@@ -296,12 +296,18 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	Xref = sla.solve_triangular(Lref, B.T, lower=True).T
 	assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 	# the same solve with the K-pass workspace
-	wb = int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, nb))
-	assert (wb == 0) == (n <= (nb if nb > 0 else 512))
-	Bw = dev(B)
-	wk = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda:0")
-	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), L.stream_ptr()), "trsm")
-	assert rel_err(Bw.cpu().numpy(), Xref) < 1e-11
+	# (below n = 32768 the library keeps the right-looking sweep; stpy_tune(5, 2) forces the left-looking form)
+	assert int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, nb)) == 0
+	lib.stpy_tune(5, 2)
+	try:
+		wb = int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, nb))
+		assert (wb == 0) == (n <= (nb if nb > 0 else 512))
+		Bw = dev(B)
+		wk = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda:0")
+		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), L.stream_ptr()), "trsm")
+		assert rel_err(Bw.cpu().numpy(), Xref) < 1e-11
+	finally:
+		lib.stpy_tune(5, 0)
 	y = rng.normal(size=n)
 	yd, zd, ad = dev(y), torch.empty(n, dtype=torch.float64, device="cuda:0"), torch.empty(n, dtype=torch.float64, device="cuda:0")
 	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
