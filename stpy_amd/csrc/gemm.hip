@@ -27,7 +27,10 @@
 
 namespace stpy {
 
-constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+// K tile: one 128-byte row per operand row (16 doubles / 32 floats), so both types share the LDS byte layout,
+// the LDS-DMA pieces and the swizzle
+template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof(T); };
 int g_gemm_stagger = 0;
 int g_gemm_exp = 0;        // timing experiments only (results are wrong when != 0)
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
@@ -145,13 +148,14 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	typedef typename MM::v4 v4;
 	typedef typename MM::v2 v2;
 	constexpr int CH = 16 / sizeof(T);        // elements per 16-byte chunk
+	constexpr int BK = KTile<T>::BK;
 	constexpr int CPR = BK / CH;              // chunks per tile row
 	constexpr int RPP = NTHREADS / CPR;       // rows staged per pass
 	constexpr int NP = BM / RPP;              // passes per operand
 	constexpr int PAD = 16 / sizeof(T);       // one 16-byte chunk of padding per LDS row
 	constexpr int LLD = BK + PAD;
 	typedef T vch __attribute__((ext_vector_type(CH)));
-	constexpr bool DMA = !GUARD && sizeof(T) == 8;      // LDS-DMA staging (unpadded, swizzled rows)
+	constexpr bool DMA = !GUARD;                        // LDS-DMA staging (unpadded, swizzled rows)
 	constexpr int RLD = DMA ? BK : LLD;                 // LDS row stride actually used
 
 	__shared__ __attribute__((aligned(16))) T smem[2 * (BM + BN) * LLD];
@@ -245,8 +249,8 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			const int r = wv * 32 + i * 8 + (lane >> 3);
 			const int f = (((r >> 1) & 3) << 1) | ((r >> 3) & 1);
 			const int c = (lane & 7) ^ f;
-			dma_a[i] = p.A + (int64_t)(row0 + r) * p.lda + c * 2;
-			dma_b[i] = p.B + (int64_t)(col0 + r) * p.ldb + c * 2;
+			dma_a[i] = p.A + (int64_t)(row0 + r) * p.lda + c * CH;
+			dma_b[i] = p.B + (int64_t)(col0 + r) * p.ldb + c * CH;
 		}
 	}
 	// One LDS-DMA wave-instruction, issued through inline asm ON PURPOSE: with the builtin, hipcc
@@ -319,21 +323,22 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			if (DMA) dma_issue(buf ^ 1, kbeg + (kt + 1) * BK);
 			else gload(kbeg + (kt + 1) * BK);
 		}
-		const T* as = As + (buf * BM + wm * 64 + r16) * RLD + (DMA ? 0 : g * 4);
-		const T* bs = Bs + (buf * BN + wn * 64 + r16) * RLD + (DMA ? 0 : g * 4);
+		const T* as = As + (buf * BM + wm * 64 + r16) * RLD;
+		const T* bs = Bs + (buf * BN + wn * 64 + r16) * RLD;
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			// keep the two halves' fragments from being live together (32 instead of 64 VGPRs)
 			if (h == 1) __builtin_amdgcn_sched_barrier(0);
-			v2 fa[4], fb[4];
-			const int hoff = DMA ? (((2 * g + h) ^ fsw) * 2) : h * 2;
+			// lane group g owns 16-byte chunks 2g and 2g+1 of its rows: CH consecutive k each, one MFMA per k
+			vch fa[4], fb[4];
+			const int hoff = ((2 * g + h) ^ (DMA ? fsw : 0)) * CH;
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
-				fa[t] = *(const v2*)(as + t * 16 * RLD + hoff);
-				fb[t] = *(const v2*)(bs + t * 16 * RLD + hoff);
+				fa[t] = *(const vch*)(as + t * 16 * RLD + hoff);
+				fb[t] = *(const vch*)(bs + t * 16 * RLD + hoff);
 			}
 #pragma unroll
-			for (int s = 0; s < 2; ++s)
+			for (int s = 0; s < CH; ++s)
 #pragma unroll
 				for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -632,7 +637,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	int64_t kchunk = 0;
 	if (ksplit > 1) {
 		if (!plain || !split_work) { set_error("gemm_nt: split-K needs a plain product (modes 0/1) and a workspace"); return -12; }
-		kchunk = ((k + ksplit - 1) / ksplit + BK - 1) / BK * BK;
+		kchunk = ((k + ksplit - 1) / ksplit + KTile<T>::BK - 1) / KTile<T>::BK * KTile<T>::BK;
 		ksplit = (int)((k + kchunk - 1) / kchunk);          // every pass starts inside [0, k)
 	}
 	if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) { set_error("gemm_nt: dimension exceeds int32"); return -2; }
@@ -693,11 +698,11 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	// Only worth its cost (half a tile, once) when the launch runs for several rounds.
 	{
 		const int64_t real_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n;
-		const int64_t kt = (k + BK - 1) / BK;
+		const int64_t kt = (k + KTile<T>::BK - 1) / KTile<T>::BK;
 		p.stagger = (g_gemm_stagger && real_tiles >= 8 * 512) ? (int)(kt * 64 * 64) : 0;     // kt * 64 MFMAs * 64 cycles = half of a two-wave tile
 	}
 	constexpr int CH = 16 / sizeof(T);
-	const bool aligned = (m % BM == 0) && (n % BN == 0) && (k % BK == 0) && (lda % CH == 0) && (ldb % CH == 0) &&
+	const bool aligned = (m % BM == 0) && (n % BN == 0) && (k % KTile<T>::BK == 0) && (lda % CH == 0) && (ldb % CH == 0) &&
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)

@@ -158,8 +158,8 @@ void gram_kernel(GramArgs<T> p)
 // NT contraction, so it runs on the GEMM of gemm.hip with the kernel function fused into its store
 // epilogue: the fp64 vector ALU -- the bottleneck of the tile kernel above, which needs ~60
 // instructions per element -- is left with the ~25 of the exp.  The points are first gathered
-// (column subset), scaled by the inverse lengthscales and zero-padded to a multiple of 16
-// coordinates into the caller's workspace, together with their squared norms.
+// (column subset), scaled by the inverse lengthscales and zero-padded to a whole K tile (16 doubles / 32 floats)
+// of coordinates into the caller's workspace, together with their squared norms.
 // Matern 1/2 keeps the direct-difference tile kernel: exp(-r) has a first-order term in r, and
 // r from the norm expansion is only good to ~1e-8 on coincident points.
 // ------------------------------------------------------------------------------------------
@@ -184,7 +184,8 @@ static inline int64_t align16(int64_t b) { return (b + 15) & ~(int64_t)15; }
 
 int64_t gram_workspace_bytes(int64_t n, int64_t q, int d, size_t esz)
 {
-	const int64_t dpad = (d + 15) / 16 * 16;
+	const int64_t kp = 128 / (int64_t)esz;           // one K tile of the GEMM: 16 doubles / 32 floats
+	const int64_t dpad = (d + kp - 1) / kp * kp;
 	return align16(n * dpad * esz) + align16(q * dpad * esz) + align16(n * esz) + align16(q * esz);
 }
 
@@ -199,7 +200,8 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 	if (kind == STPY_K_POLY && (degree < 1 || degree > 64)) { set_error("gram: polynomial degree %d out of range [1, 64]", degree); return -1; }
 	if (kind != STPY_K_POLY && degree != 0) { set_error("gram: unknown kernel kind %d", kind | (degree << 8)); return -1; }
 	if (work && kind != STPY_K_MATERN12 && kind >= STPY_K_SE && kind <= STPY_K_LINEAR) {
-		const int dpad = (d + 15) / 16 * 16;
+		constexpr int KP = 128 / (int)sizeof(T);
+		const int dpad = (d + KP - 1) / KP * KP;
 		char* w = (char*)work;
 		T* as = (T*)w; w += align16(n * (int64_t)dpad * sizeof(T));
 		T* bs = (T*)w; w += align16(q * (int64_t)dpad * sizeof(T));
@@ -238,7 +240,8 @@ int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_
 {
 	if (n <= 0) return 0;
 	if (kind < STPY_K_SE || kind > STPY_K_MATERN52) { set_error("lml_weight: kernel kind %d has no lengthscale gradient", kind); return -1; }
-	const int dpad = (d + 15) / 16 * 16;
+	constexpr int KP = 128 / (int)sizeof(T);
+	const int dpad = (d + KP - 1) / KP * KP;
 	char* w = (char*)work;
 	T* as = (T*)w; w += align16(n * (int64_t)dpad * sizeof(T));
 	w += align16(n * (int64_t)dpad * sizeof(T));
