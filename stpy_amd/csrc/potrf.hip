@@ -422,25 +422,30 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 template <typename T>
 int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st)
 {
+	// nb = 0: the panel width follows the size of what is LEFT (potrf_auto_nb): wide panels while the trailing
+	// update is long enough to hide the next panel's latency-bound chain, narrower ones towards the end
+	const bool adaptive = nb <= 0;
 	if (nb <= 0) nb = potrf_auto_nb(n);
 	if (nb % IB != 0) { set_error("potrf: nb must be a multiple of %d", IB); return -7; }
 	HIPCHK(hipMemsetAsync(info, 0, sizeof(int32_t), st));
-	const int64_t ldp = nb;
+	const int64_t ldp = nb;                                         // widest panel (the first one)
 	T* Pbuf[2] = {work, work + n * ldp};
 	int rc = lookahead_init();
 	if (rc) return rc;
 	hipStream_t side = g_la.side;
+	auto width = [&](int64_t left) { const int64_t w = adaptive ? potrf_auto_nb(left) : nb; return left < w ? left : w; };
 
-	rc = factor_panel<T>(n, 0, (n < nb) ? n : nb, A, lda, winv, Pbuf[0], ldp, info, st);
+	int64_t wk = width(n);                                          // width of the current panel
+	rc = factor_panel<T>(n, 0, wk, A, lda, winv, Pbuf[0], ldp, info, st);
 	if (rc) return rc;
 	int cur = 0;
-	for (int64_t k = 0; k + nb < n; k += nb) {
-		const int64_t r = k + nb;                                   // first row/column of the trailing matrix
-		const int64_t nkb = (n - r < nb) ? (n - r) : nb;            // width of the next panel
+	for (int64_t k = 0; k + wk < n;) {
+		const int64_t r = k + wk;                                   // first row/column of the trailing matrix
+		const int64_t nkb = width(n - r);                           // width of the next panel
 		T* Pk = Pbuf[cur];
 		{   // next panel's block column (all rows below r)
-			ProfScope ps(TAG_SYRK, 2.0 * (double)(n - r) * (double)nkb * (double)nb - (double)nkb * (double)nkb * (double)nb, st);
-			rc = gemm_nt<T>(n - r, nkb, nb, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, st);
+			ProfScope ps(TAG_SYRK, 2.0 * (double)(n - r) * (double)nkb * (double)wk - (double)nkb * (double)nkb * (double)wk, st);
+			rc = gemm_nt<T>(n - r, nkb, wk, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
 		HIPCHK(hipEventRecord(g_la.col_ready, st));
@@ -450,8 +455,8 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		HIPCHK(hipEventRecord(g_la.panel_done, side));
 		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
 			const int64_t r2 = r + nkb;
-			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)nb, st);      // lower triangle: m^2 k
-			rc = gemm_nt<T>(n - r2, n - r2, nb, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, st);
+			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, st);      // lower triangle: m^2 k
+			rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, st);
 			if (rc) return rc;
 		}
 		HIPCHK(hipStreamWaitEvent(st, g_la.panel_done, 0));
@@ -459,6 +464,8 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		// trailing update has finished reading it: it waits on the next col_ready, which is
 		// recorded on `st` after this update -- stream order gives that for free.
 		cur ^= 1;
+		k = r;
+		wk = nkb;
 	}
 	return 0;
 }

@@ -206,5 +206,7 @@ if __name__ == "__main__":
 		for n, nb in ((8192, 512), (16384, 512), (32768, 512), (32768, 256), (32768, 1024)):
 			bench_potrf(n, nb)
 	if which == "big":
-		for nb in (1024, 1536, 2048, 3072, 1024):
+		for nb in (0, 1024, 0, 1024):
 			bench_potrf(65536, nb)
+		for nb in (0, 512, 0, 512):
+			bench_potrf(32768, nb)
