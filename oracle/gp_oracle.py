@@ -282,6 +282,19 @@ def log_marginal(x, y, spec, s, overrides=None, weight=1.0):
 	return np.array([[0.5 * float((z.T @ z)[0, 0]) + 0.5 * weight * logdet]])
 
 
+def norm(x, alpha, spec):
+	"""gauss_procc.py:179-184: sqrt(alpha^T k(x,x) alpha)."""
+	a = np.asarray(alpha, dtype=np.float64).reshape(-1, 1)
+	return np.sqrt(a.T @ kernel(x, x, spec) @ a)
+
+
+def beta(x, spec, s, delta=1e-3, norm=1):
+	"""gauss_procc.py:186-196: s * norm + sqrt(2 log(1/delta + log(det K / s^n)))."""
+	K = gram_train(x, spec, s)
+	n = K.shape[0]
+	return s * norm + np.sqrt(2 * np.log(1. / delta + np.log(np.linalg.det(K) / s ** n)))
+
+
 # --------------------------------------------------------------------------------------------
 # Random Fourier features  (stpy/embeddings/embedding.py)
 # --------------------------------------------------------------------------------------------

@@ -28,6 +28,8 @@ Differences a caller can observe, all deliberate:
   * robust losses, sampling helpers, gradients, UCB optimisation are outside the hot path.
 """
 import numpy as np
+import math
+
 import torch
 
 from .. import _lib
@@ -246,11 +248,25 @@ class GaussianProcess:
 		return self.K
 
 	def norm(self):
-		"""gauss_procc.py:179-184: sqrt(alpha^T k(x,x) alpha)."""
+		"""gauss_procc.py:179-184: sqrt(alpha^T k(x,x) alpha).  With (k + s^2 I) alpha = y this is
+		sqrt(alpha^T y - s^2 alpha^T alpha): no n x n matrix is formed."""
 		if not self.fitted:
 			return None
-		Kxx = self.kernel_object.kernel(self._xd, self._xd)
-		return _lib.like_input(torch.sqrt(self._alpha.reshape(1, -1) @ Kxx @ self._alpha.reshape(-1, 1)), self.x)
+		a = self._alpha.reshape(-1)
+		val = torch.dot(a, self._yd.reshape(-1)) - float(self.s) ** 2 * torch.dot(a, a)
+		return _lib.like_input(torch.sqrt(val).reshape(1, 1), self.x)
+
+	def beta(self, delta=1e-3, norm=1):
+		"""gauss_procc.py:186-196: s * norm + sqrt(2 log(1/delta + log(det K / s^n))), K = k(x,x) + s^2 I.
+		log det K comes from the factor (2 sum log L_ii), so nothing overflows at sizes where det K would."""
+		lib = _lib.load()
+		L = self._L
+		out2 = torch.empty((2,), dtype=L.dtype, device=L.device)
+		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), None, _lib.ptr(out2),
+										_lib.stream_ptr()), "stpy_logdet_quad")
+		log_ratio = 2.0 * out2[0] - self.n * math.log(float(self.s))
+		val = float(self.s) * norm + torch.sqrt(2.0 * torch.log(1.0 / delta + log_ratio))
+		return _lib.like_input(val.reshape(()), self.x)
 
 	# ------------------------------------------------------------------ prediction
 	def execute(self, xtest):

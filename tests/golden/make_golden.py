@@ -364,6 +364,15 @@ def main():
 	save("K2_more_kernels", a=a, b=b, x7=x7, groups_flat=np.array([0, 1, -1, 2, -1, 3, 4]), p_ard_gamma=N(ag), p_gamma_per_group=np.array(gpg),
 		 p_ard_per_group=N(apg), gp_x=x, gp_y=y, gp_xtest=xtest, gp_mu=N(mu), gp_std=N(std), gp_lml=lml(GP), **out)
 
+	# ---------------------------------------------------------------- B1: beta() and norm() (gauss_procc.py:179-196)
+	rng3 = np.random.RandomState(20241103)
+	x = rng3.uniform(-1, 1, size=(14, 2)); y = np.sin(x.sum(axis=1, keepdims=True)) + 0.05 * rng3.normal(size=(14, 1))
+	GP = GaussianProcess(gamma=0.7, s=0.3, kappa=1.2, kernel_name="squared_exponential", d=2)
+	GP.fit_gp(T(x), T(y))
+	save("B1_beta_norm", x=x, y=y, gamma=np.array(0.7), s=np.array(0.3), kappa=np.array(1.2),
+		 beta_default=N(GP.beta()), beta_d01_n2=N(GP.beta(delta=0.1, norm=2.0)), norm=N(GP.norm()),
+		 lcb=N(GP.lcb(T(x[:5]))), ucb=N(GP.ucb(T(x[:5]))))
+
 
 if __name__ == "__main__":
 	main()

@@ -489,6 +489,24 @@ def test_G12_kernelized_features(S):
 		KernelizedFeatures(embedding=emb, m=m, primal=False)
 
 
+def test_B1_beta_norm_bounds(S):
+	"""beta(), norm(), lcb(), ucb() (gauss_procc.py:119-134, :179-196) against the reference's outputs."""
+	g = golden("B1_beta_norm")
+	GP = S.GaussianProcess(gamma=float(g["gamma"]), s=float(g["s"]), kappa=float(g["kappa"]), kernel_name="squared_exponential", d=2)
+	assert GP.norm() is None
+	GP.fit_gp(T(g["x"]), T(g["y"]))
+	assert abs(float(GP.norm()) - g["norm"].item()) / g["norm"].item() < TOL
+	assert abs(float(GP.beta()) - g["beta_default"].item()) / g["beta_default"].item() < TOL
+	assert abs(float(GP.beta(delta=0.1, norm=2.0)) - g["beta_d01_n2"].item()) / g["beta_d01_n2"].item() < TOL
+	assert rel_err(N(GP.lcb(T(g["x"][:5]))), g["lcb"]) < TOL and rel_err(N(GP.ucb(T(g["x"][:5]))), g["ucb"]) < TOL
+	# a size where det K itself overflows a double: the factor-based form stays finite
+	rng = np.random.RandomState(5)
+	x = rng.uniform(-1, 1, size=(3000, 2))
+	GP2 = S.GaussianProcess(gamma=0.1, s=30.0, kappa=1.0, kernel_name="squared_exponential", d=2)
+	GP2.fit_gp(T(x), T(np.sin(x.sum(axis=1, keepdims=True))))
+	assert np.isfinite(float(GP2.beta()))
+
+
 def test_edge_cases_closed_forms(S):
 	"""Anchors the reference's tests lack: N = 1 closed forms, one test point,
 	sizes around the 128 tile edge, coincident training points, an empty test set."""

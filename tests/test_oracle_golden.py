@@ -243,6 +243,18 @@ def test_G12_kernelized_features():
 	assert rel_err(O.linear(Qa, Qb, group=[0]), g["kernel_head"]) < 1e-13 and g["kernel_head"].shape == (7, 5)
 
 
+def test_B1_beta_norm():
+	g = golden("B1_beta_norm")
+	spec = se_spec(g["gamma"], g["kappa"])
+	s = float(g["s"])
+	L, alpha = O.fit(g["x"], g["y"], spec, s)
+	assert abs(O.norm(g["x"], alpha, spec).item() - g["norm"].item()) / g["norm"].item() < TOL
+	assert abs(O.beta(g["x"], spec, s) - g["beta_default"].item()) / g["beta_default"].item() < TOL
+	assert abs(O.beta(g["x"], spec, s, delta=0.1, norm=2.0) - g["beta_d01_n2"].item()) / g["beta_d01_n2"].item() < TOL
+	mu, std = O.mean_std(g["x"], L, alpha, g["x"][:5], spec)
+	assert rel_err(mu - 2 * std, g["lcb"]) < TOL and rel_err(mu + 2 * std, g["ucb"]) < TOL
+
+
 def test_H1_helpers():
 	g = golden("H1_helpers")
 	assert np.array_equal(O.interval(5, 2), g["interval_5_2"])
