@@ -147,6 +147,16 @@ class GaussianProcess:
 		return mu + 2 * s
 
 	# ------------------------------------------------------------------ factorisation
+	@staticmethod
+	def _add_noise_gram(K, Sigma):
+		"""K += Sigma^T Sigma = K - (-Sigma^T)(Sigma^T)^T: one stpy_gemm_nt in subtract mode."""
+		lib = _lib.load()
+		St = _lib.to_device(Sigma, K.dtype).t().contiguous()
+		nSt = -St
+		n = K.shape[0]
+		_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(K.dtype), n, n, St.shape[1], _lib.ptr(nSt), nSt.stride(0), _lib.ptr(St), St.stride(0),
+									_lib.ptr(K), K.stride(0), 1, 0, _lib.stream_ptr()), "stpy_gemm_nt")
+
 	def _factor(self, xd, kwargs=None, Sigma=None):
 		"""K_theta = k(x,x) + s^2 I (or + Sigma^T Sigma) -> in-place Cholesky.  Returns (L, winv)."""
 		lib = _lib.load()
@@ -156,10 +166,9 @@ class GaussianProcess:
 		if Sigma is None:
 			self.kernel_object._kernel_into(xd, xd, K, kwargs, diag_add=float(self.s) ** 2, lower_only=True)
 		else:
-			# general noise matrix: off the hot path, one device matmul (gauss_procc.py:163)
+			# general noise matrix (gauss_procc.py:163): K += Sigma^T Sigma through the NT product
 			self.kernel_object._kernel_into(xd, xd, K, kwargs)
-			Sd = _lib.to_device(Sigma, xd.dtype)
-			K.add_(Sd.T @ Sd)
+			self._add_noise_gram(K, Sigma)
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=xd.dtype, device=xd.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, n, self.nb)),), dtype=torch.uint8, device=xd.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
@@ -234,8 +243,7 @@ class GaussianProcess:
 			self.kernel_object._kernel_into(xd, xd, K, None, diag_add=float(self.s) ** 2)
 		else:
 			self.kernel_object._kernel_into(xd, xd, K, None)
-			Sd = _lib.to_device(self._Sigma, xd.dtype)
-			K.add_(Sd.T @ Sd)
+			self._add_noise_gram(K, self._Sigma)
 		return _lib.like_input(K, self.x)
 
 	@property
@@ -253,7 +261,16 @@ class GaussianProcess:
 		if not self.fitted:
 			return None
 		a = self._alpha.reshape(-1)
-		val = torch.dot(a, self._yd.reshape(-1)) - float(self.s) ** 2 * torch.dot(a, a)
+		if self._Sigma is None:
+			noise = float(self.s) ** 2 * torch.dot(a, a)
+		else:                                   # general noise matrix: alpha^T Sigma^T Sigma alpha = |Sigma alpha|^2
+			lib = _lib.load()
+			Sd = _lib.to_device(self._Sigma, a.dtype).contiguous()
+			v = torch.empty((1, Sd.shape[0]), dtype=a.dtype, device=a.device)
+			_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(a.dtype), 1, Sd.shape[0], Sd.shape[1], _lib.ptr(a), a.shape[0], _lib.ptr(Sd), Sd.stride(0),
+										_lib.ptr(v), v.stride(0), 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
+			noise = torch.dot(v.reshape(-1), v.reshape(-1))
+		val = torch.dot(a, self._yd.reshape(-1)) - noise
 		return _lib.like_input(torch.sqrt(val).reshape(1, 1), self.x)
 
 	def beta(self, delta=1e-3, norm=1):

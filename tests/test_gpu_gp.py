@@ -507,6 +507,37 @@ def test_B1_beta_norm_bounds(S):
 	assert np.isfinite(float(GP2.beta()))
 
 
+def test_general_noise_matrix(S):
+	"""fit_gp(x, y, Sigma): K = k(x,x) + Sigma^T Sigma (gauss_procc.py:151-163) for a non-diagonal Sigma."""
+	import scipy.linalg as sla
+	rng = np.random.RandomState(11)
+	n, m = 300, 40
+	x, xq = rng.uniform(-1, 1, size=(n, 3)), rng.uniform(-1, 1, size=(m, 3))
+	y = np.sin(x.sum(axis=1, keepdims=True)) + 0.1 * rng.normal(size=(n, 1))
+	Sigma = np.triu(0.02 * rng.normal(size=(n, n)), 1) + np.diag(rng.uniform(0.2, 0.5, size=n))
+	spec = [("squared_exponential", {"gamma": 0.9, "kappa": 1.3}, "-")]
+	GP = S.GaussianProcess(gamma=0.9, s=0.3, kappa=1.3, kernel_name="squared_exponential", d=3)
+	GP.fit_gp(T(x), T(y), Sigma=T(Sigma))
+	K = O.kernel(x, x, spec) + Sigma.T @ Sigma
+	assert rel_err(N(GP.get_kernel()), K) < 1e-12
+	L = sla.cholesky(K, lower=True)
+	alpha = sla.cho_solve((L, True), y)
+	Ks = O.kernel(x, xq, spec)
+	V = sla.solve_triangular(L, Ks.T, lower=True)
+	mu_ref = Ks @ alpha
+	std_ref = np.sqrt(1.3 - np.sum(V * V, axis=0)).reshape(-1, 1)
+	mu, std = GP.mean_std(T(xq))
+	assert rel_err(N(mu), mu_ref) < TOL and rel_err(N(std), std_ref) < TOL
+	assert abs(float(GP.norm()) - np.sqrt(alpha.T @ O.kernel(x, x, spec) @ alpha).item()) < 1e-9
+	# Sigma = s I reproduces the default path
+	GP1 = S.GaussianProcess(gamma=0.9, s=0.3, kappa=1.3, kernel_name="squared_exponential", d=3)
+	GP1.fit_gp(T(x), T(y))
+	GP2 = S.GaussianProcess(gamma=0.9, s=0.3, kappa=1.3, kernel_name="squared_exponential", d=3)
+	GP2.fit_gp(T(x), T(y), Sigma=T(0.3 * np.eye(n)))
+	m1, s1 = GP1.mean_std(T(xq)); m2, s2 = GP2.mean_std(T(xq))
+	assert rel_err(N(m2), N(m1)) < 1e-10 and rel_err(N(s2), N(s1)) < 1e-10
+
+
 def test_edge_cases_closed_forms(S):
 	"""Anchors the reference's tests lack: N = 1 closed forms, one test point,
 	sizes around the 128 tile edge, coincident training points, an empty test set."""
