@@ -79,6 +79,7 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
 extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking;
+extern int g_potrf_diag_first_below;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
 template <typename T>

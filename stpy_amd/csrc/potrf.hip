@@ -357,6 +357,7 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 // Side stream + events for the look-ahead (one set per process, created on first use; the side
 // stream has the highest priority so the small panel kernels are dispatched ahead of the queued
 // trailing-update workgroups as CU slots free up).
+int g_potrf_diag_first_below = 8192;     // stpy_tune key 7
 static LookAhead g_la;
 
 LookAhead* lookahead_state() { return &g_la; }
@@ -383,7 +384,8 @@ int lookahead_init()
 // the panels to its left), left-looking over 128-column blocks.  Writes L into A and into the
 // panel workspace P (n x nb, leading dimension nb, rows indexed globally).
 template <typename T>
-static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* winv, T* P, int64_t ldp, int32_t* info, hipStream_t st)
+static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* winv, T* P, int64_t ldp, int32_t* info, hipStream_t st,
+                        hipEvent_t first_diag = nullptr)
 {
 	int rc;
 	for (int64_t c = k; c < k + kb; c += IB) {
@@ -399,6 +401,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st);
 		}
 		if (rc) return rc;
+		if (c == k && first_diag && hipEventRecord(first_diag, st) != hipSuccess) { set_error("potrf: event record failed"); return -1003; }
 		if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
 			ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
 			rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
@@ -450,9 +453,14 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		}
 		HIPCHK(hipEventRecord(g_la.col_ready, st));
 		HIPCHK(hipStreamWaitEvent(side, g_la.col_ready, 0));
-		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side);
+		// A short trailing update cannot hide the panel chain, and the chain's first kernel -- one workgroup that needs
+		// 83 KiB of LDS -- waits ~200 us for a CU slot once the update's workgroups have flooded the chip (kernel trace,
+		// tools/potrf_only.py).  Below the threshold the update therefore starts only after that kernel has run.
+		const bool diag_first = (n - r) <= g_potrf_diag_first_below;
+		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, diag_first ? g_la.trail_done : nullptr);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(g_la.panel_done, side));
+		if (diag_first) HIPCHK(hipStreamWaitEvent(st, g_la.trail_done, 0));
 		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
 			const int64_t r2 = r + nkb;
 			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, st);      // lower triangle: m^2 k

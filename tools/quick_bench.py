@@ -182,6 +182,13 @@ def leftlook():
 
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "diagfirst":
+		for n in (8192, 16384, 32768, 65536):
+			for thr in (1, 1 << 30, 1, 1 << 30):
+				lib.stpy_tune(7, thr)
+				print("diag-first below %d:" % thr, end=" ")
+				bench_potrf(n, 0)
+		lib.stpy_tune(7, 8192)
 	if which == "fixed":
 		fixed_cost()
 	if which == "leftlook":
