@@ -48,7 +48,7 @@ def flops_fit_predict(n, m):
 	return n ** 3 / 3.0 + 2.0 * n * n + float(n) * n * m + 4.0 * n * m
 
 
-def cpu_baseline(d, budget_n=12288, budget_m=2048):
+def cpu_baseline(d, budget_n=16384, budget_m=2048):
 	"""CPU oracle (port) on a bounded sample of the same workload; ~10-30 s of host work."""
 	from oracle import gp_oracle as O           # checker/baseline only -- never on the product path
 	n, m = budget_n, budget_m
