@@ -299,6 +299,36 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	// ---- same wave read W_kj back from there
 	if (wave < NSB - 1) {
 		const int j = wave;
+		if constexpr (sizeof(T) == 8) {
+			// fp64: the C/D fragment of a finished block (reg s of lane l = element [(l>>4) + 4s][l&15]) IS the B operand
+			// of k-step s, so the blocks W_kj this wave has produced stay in registers and feed the next products
+			// directly -- no trip through memory between the steps of the chain.  Loops are indexed relative to j so
+			// that every register array index is a compile-time constant.
+			v4 wcol[NSB];
+#pragma unroll
+			for (int ii = 1; ii < NSB; ++ii) {
+				const int i = j + ii;
+				if (i < NSB) {
+					v4 t = v4{0, 0, 0, 0};
+#pragma unroll
+					for (int kk = 0; kk < ii; ++kk) {
+						const int k = j + kk;
+#pragma unroll
+						for (int s4 = 0; s4 < 4; ++s4) {
+							const T a = S[tri(i * SB + r16, k * SB + 4 * s4 + g)];                      // L_ik[r16][kk]
+							const T b = (kk == 0) ? WD[(j * SB + 4 * s4 + g) * WLD + r16] : wcol[kk][s4];    // W_kj[kk][c]
+							t = MM::mma(a, b, t);
+						}
+					}
+					v4 w = v4{0, 0, 0, 0};
+#pragma unroll
+					for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], t[s4], w);
+					wcol[ii] = w;
+#pragma unroll
+					for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
+				}
+			}
+		} else {
 		T* sc = SC + wave * SB * WLD;
 		for (int i = j + 1; i < NSB; ++i) {
 			v4 t = v4{0, 0, 0, 0};
@@ -312,24 +342,19 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 				}
 			}
 			v4 w = v4{0, 0, 0, 0};
-			if (sizeof(T) == 8) {
-				// fp64 C/D map: reg s of lane l is T[(l>>4) + 4s][l&15] -- already the B operand of k-step s
 #pragma unroll
-				for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], t[s4], w);
-			} else {
+			for (int q = 0; q < 4; ++q) sc[MM::crow(lane, q) * WLD + r16] = t[q];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 #pragma unroll
-				for (int q = 0; q < 4; ++q) sc[MM::crow(lane, q) * WLD + r16] = t[q];
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-#pragma unroll
-				for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], sc[(4 * s4 + g) * WLD + r16], w);
-			}
+			for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], sc[(4 * s4 + g) * WLD + r16], w);
 #pragma unroll
 			for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
 			// the next step of this wave re-reads these values: stores drained, then ordered before the loads
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		}
 		}
 	}
 }
