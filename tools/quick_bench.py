@@ -55,7 +55,7 @@ def bench_potrf(n, nb):
 		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), nb, L.ptr(info), L.stream_ptr()), "potrf")
 	t2, _ = timeit(f, reps=2)
 	tp = t2 - t
-	print("potrf n=%d nb=%d: %.3f s  %.1f TF/s  info=%d" % (n, nb, tp, n ** 3 / 3.0 / tp / 1e12, int(info.item())), flush=True)
+	print("potrf n=%d nb=%d: %.3f ms  %.1f TF/s  info=%d" % (n, nb, tp * 1e3, n ** 3 / 3.0 / tp / 1e12, int(info.item())), flush=True)
 
 
 def ab_gemm():
