@@ -467,57 +467,92 @@ class GaussianProcess:
 		return _lib.like_input(val.reshape(1, 1), self.x), (L, winv, z)
 
 	def _log_marginal_grads(self, kernel, X, weight, state, params):
-		"""d/dtheta of the value above for every entry of ``params`` (same order), as CPU/GPU tensors shaped like the parameters."""
+		"""
+		d/dtheta of the value above for every entry of ``params`` (same order), as tensors shaped like the parameters.
+
+		G = w K^-1 - alpha alpha^T (stpy_potri).  The kernel is a chain of items combined by + and *
+		(kernels.py:146-157), every item a sum of terms kappa phi(scaled distance).  For a lengthscale l_m of
+		a term t of item i:   dK/dl_m = M_i o kappa F_t u_m^2 / l_m,   u_m the scaled coordinate difference, F_t the
+		family's derivative factor, and M_i = dK/dK_i the elementwise product of everything item i is multiplied
+		with (the value accumulated before it when its own operation is *, and every later item joined by *).
+		So H = G o kappa F_t (stpy_lml_weight) o M_i (stpy_gram with the multiply combine), and
+		sum_ij H_ij u_m^2 = 2 [ sum_i xs_im^2 h_i - xs_m^T H xs_m ] with h = H 1 -- one stpy_gemm_nt of H
+		against [Xs | 1].
+		"""
 		lib = _lib.load()
-		if kernel.kernel_items != 1:
-			raise NotImplementedError("evidence gradients are provided for single-item kernels (no + / * composites yet)")
+		from ..kernels import _dev_const
 		L, winv, z = state
 		n = L.shape[0]
 		dt = _lib.dtype_code(L.dtype)
-		it = kernel._resolve(dict(X) if X else {})[0]
-		if len(it['terms']) != 1 or it['premap'] is not None:
-			raise NotImplementedError("evidence gradients are provided for single-term kernels (no additive groups / full covariance yet)")
-		if (it['kind'] & 0xff) in (_lib.K_LINEAR, _lib.K_POLY):
-			raise NotImplementedError("dot-product kernels have no lengthscale gradient")
+		items = kernel._resolve(dict(X) if X else {})
 		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
 		st = _lib.stream_ptr
+		xd = self._xd
 		alpha = self._backward_z(L, winv, z)
 		Kinv = torch.empty((n, n), dtype=L.dtype, device=L.device)
 		work = torch.empty((n, n), dtype=L.dtype, device=L.device)
 		_lib.check(lib.stpy_potri(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(work), st()), "stpy_potri")
-		del work
 		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), Kinv.stride(0), st()), "stpy_symmetrize_lower")
 		trace_G = w * Kinv.diagonal().sum() - torch.dot(alpha, alpha)                    # tr(w K^-1 - alpha alpha^T)
-		group = it['group']
-		xd = self._xd
-		identity = (group == list(range(xd.shape[1])))
-		from ..kernels import _dev_const
-		cols = None if identity else _dev_const(group, None, xd.device, int32=True)
-		inv_ls = _dev_const(it['inv_ls'], xd.dtype, xd.device)
-		ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
-		_lib.check(lib.stpy_lml_weight(it['kind'], dt, _lib.ptr(xd), n, xd.stride(0), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
-									   it['kappa'], w, _lib.ptr(alpha), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(ws), st()), "stpy_lml_weight")
-		H = Kinv                                                                          # now (w K^-1 - alpha alpha^T) o kappa F
-		xs = (xd if identity else xd[:, group]) * inv_ls                                  # scaled coordinates (n, dg)
-		dg = xs.shape[1]
-		XT = torch.cat([xs.T, torch.ones((1, n), dtype=xs.dtype, device=xs.device)]).contiguous()      # (dg + 1, n): NT operand
-		P = torch.empty((n, dg + 1), dtype=xs.dtype, device=xs.device)
-		_lib.check(lib.stpy_gemm_nt(dt, n, dg + 1, n, _lib.ptr(H), H.stride(0), _lib.ptr(XT), XT.stride(0), _lib.ptr(P), P.stride(0), 0, 0, st()), "stpy_gemm_nt")
-		h = P[:, dg]
-		# sum_ij H_ij u_m^2 = 2 [ sum_i xs_im^2 h_i - xs_m^T H xs_m ];  d/d(ls_m) = that / (2 ls_m)
-		S = (xs * xs * h.unsqueeze(1)).sum(dim=0) - (xs * P[:, :dg]).sum(dim=0)
-		g_ls = S * inv_ls                                                                  # per coordinate of the group
+
+		wanted = [(key, name, t) for (key, name, t) in params if key != "likelihood"]
+		single = len(items) == 1 and len(items[0]['terms']) == 1
+		acc = {(key, name): torch.zeros(t.numel(), dtype=L.dtype, device=L.device) for (key, name, t) in wanted}
+		tmp = None
+		for i, it in enumerate(items):
+			mine = [(key, name) for (key, name, _) in wanted if key == str(i)]
+			if not mine:
+				continue
+			for term in it['terms']:
+				if term['pname'] is None or (str(i), term['pname']) not in acc:
+					continue
+				if term['premap'] is not None:
+					raise NotImplementedError("evidence gradients: full-covariance kernels are not covered")
+				group = term['group']
+				identity = (group == list(range(xd.shape[1])))
+				cols = None if identity else _dev_const(group, None, xd.device, int32=True)
+				inv_ls = _dev_const(term['inv_ls'], xd.dtype, xd.device)
+				# H <- (w K^-1 - alpha alpha^T) o kappa F_t, in `work` unless this is the only term (then in place)
+				if single:
+					H = Kinv
+				else:
+					H = work
+					H.copy_(Kinv)
+				ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
+				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(xd), n, xd.stride(0), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
+											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(H), H.stride(0), _lib.ptr(ws), st()), "stpy_lml_weight")
+				# ... o M_i
+				factors = []
+				if it['op'] == "*" and i > 0:
+					factors.append(items[:i])
+				for j in range(i + 1, len(items)):
+					if items[j]['op'] == "*":
+						factors.append([items[j]])
+				for fac in factors:
+					if tmp is None:
+						tmp = torch.empty((n, n), dtype=L.dtype, device=L.device)
+					kernel._run_items(fac, xd, xd, tmp)
+					H.mul_(tmp)
+				xs = (xd if identity else xd[:, group]) * inv_ls                              # scaled coordinates (n, dg)
+				dg = xs.shape[1]
+				XT = torch.cat([xs.T, torch.ones((1, n), dtype=xs.dtype, device=xs.device)]).contiguous()      # (dg + 1, n): NT operand
+				P = torch.empty((n, dg + 1), dtype=xs.dtype, device=xs.device)
+				_lib.check(lib.stpy_gemm_nt(dt, n, dg + 1, n, _lib.ptr(H), H.stride(0), _lib.ptr(XT), XT.stride(0), _lib.ptr(P), P.stride(0), 0, 0, st()), "stpy_gemm_nt")
+				h = P[:, dg]
+				S = (xs * xs * h.unsqueeze(1)).sum(dim=0) - (xs * P[:, :dg]).sum(dim=0)
+				g_ls = S * inv_ls                                                             # d/d(lengthscale) per coordinate of the term
+				acc[(str(i), term['pname'])].index_add_(0, torch.tensor(term['pidx'], device=L.device), g_ls)
+		del work
+		for key, name, t in wanted:
+			if (key, name) not in acc or int(key) >= len(items) or not any(tm['pname'] == name for tm in items[int(key)]['terms']):
+				raise NotImplementedError("evidence gradient: kernel item %s has no '%s' lengthscale on the device path" % (key, name))
 		grads = []
 		for (key, name, t) in params:
-			if name == "gamma":
-				g = g_ls.sum().reshape(t.shape if t.dim() > 0 else ())
-			elif name == "ard_gamma":
-				full = torch.zeros(t.numel(), dtype=g_ls.dtype, device=g_ls.device)
-				full[torch.tensor(group, device=g_ls.device)] = g_ls
-				g = full.reshape(t.shape)
-			else:       # noise std: dK/ds = 2 s I
+			if key == "likelihood":      # noise std: dK/ds = 2 s I
 				sval = float(t.detach().reshape(-1)[0].item())
 				g = (sval * trace_G).reshape(t.shape if t.dim() > 0 else ())
+			else:
+				g = acc[(key, name)].reshape(t.shape if t.dim() > 0 else ())
 			grads.append(g.to(device=t.device, dtype=t.dtype))
 		return grads
 

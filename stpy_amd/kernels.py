@@ -189,25 +189,28 @@ class KernelFunction:
 			kappa = _scalar(arg['kappa']) if 'kappa' in arg else _scalar(owner.kappa)
 			group = list(arg['group']) if 'group' in arg else list(owner.group)
 
-			def term(kind, inv_ls, cols=None, k=None, offset=0.0, premap=None):
+			def term(kind, inv_ls, cols=None, k=None, offset=0.0, premap=None, pname=None, pidx=None):
+				# pname / pidx: which hyper-parameter ('gamma' / 'ard_gamma') and which of its entries sets the
+				# lengthscale of each coordinate -- what the evidence gradient scatters into
 				return dict(kind=kind, kappa=kappa if k is None else k, group=group if cols is None else list(cols), inv_ls=inv_ls,
-							offset=offset, premap=premap)
+							offset=offset, premap=premap, pname=pname, pidx=pidx)
 
 			def vec(v):
 				return torch.as_tensor(v).detach().double().reshape(-1)
 
 			if name == "squared_exponential":
 				gamma = _scalar(arg['gamma']) if 'gamma' in arg else _scalar(owner.gamma)
-				terms = [term(_lib.K_SE, [1.0 / gamma] * len(group))]
+				terms = [term(_lib.K_SE, [1.0 / gamma] * len(group), pname='gamma', pidx=[0] * len(group))]
 			elif name == "ard" and ('groups' in arg or owner.groups is not None):
 				# kernels.py:697-725: columns subset by `group`, every entry of `groups` then indexes that
 				# subset and ard_gamma; each term carries kappa, the mean is over the groups
 				g = vec(arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma)
 				groups = arg['groups'] if 'groups' in arg else owner.groups
-				terms = [term(_lib.K_SE, [1.0 / float(g[j]) for j in ga], cols=[group[j] for j in ga], k=kappa / len(groups)) for ga in groups]
+				terms = [term(_lib.K_SE, [1.0 / float(g[j]) for j in ga], cols=[group[j] for j in ga], k=kappa / len(groups),
+							  pname='ard_gamma', pidx=list(ga)) for ga in groups]
 			elif name == "ard":
 				g = vec(arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma)
-				terms = [term(_lib.K_SE, [1.0 / float(g[j]) for j in group])]                 # kernels.py:572
+				terms = [term(_lib.K_SE, [1.0 / float(g[j]) for j in group], pname='ard_gamma', pidx=list(group))]   # kernels.py:572
 			elif name == "squared_exponential_per_group":
 				# kernels.py:669-695: kappa * mean_g SE_g, and SE_g applies kappa again (the overriding one
 				# if present, else the object's)
@@ -229,11 +232,11 @@ class KernelFunction:
 			elif name == "matern":
 				gamma = _scalar(arg['gamma']) if 'gamma' in arg else _scalar(owner.gamma)
 				nu = arg['nu'] if 'nu' in arg else owner.v
-				terms = [term(self._matern_kind(nu), [1.0 / gamma] * len(group))]
+				terms = [term(self._matern_kind(nu), [1.0 / gamma] * len(group), pname='gamma', pidx=[0] * len(group))]
 			elif name == "ard_matern":
 				g = vec(arg['ard_gamma'] if 'ard_gamma' in arg else owner.ard_gamma)
 				nu = arg['nu'] if 'nu' in arg else owner.v
-				terms = [term(self._matern_kind(nu), [1.0 / float(g[j]) for j in group])]  # kernels.py:941
+				terms = [term(self._matern_kind(nu), [1.0 / float(g[j]) for j in group], pname='ard_gamma', pidx=list(group))]  # kernels.py:941
 			elif name in ("full_covariance_se", "full_covariance_matern"):
 				# kernels.py:464-549: x[:, group] @ cov, then SE (gamma = 1) / Matern on Euclidean distances;
 				# the Matern variant reads its smoothness from 'v' (not 'nu'), else the object's
@@ -289,8 +292,14 @@ class KernelFunction:
 		Device-side evaluation: a (n, d), b (q, d) and out (q, n) are tensors on this process's
 		GPU.  ``diag_add`` (s^2 of gauss_procc.py:151-163) is applied with the last launch.
 		"""
-		lib = _lib.load()
 		items = self._resolve(dict(kwargs) if kwargs else {})
+		return self._run_items(items, a, b, out, diag_add, lower_only)
+
+	def _run_items(self, items, a, b, out, diag_add=0.0, lower_only=False):
+		"""Evaluates a list of resolved items (the first one's operation is taken as "set") into ``out``."""
+		lib = _lib.load()
+		if items and items[0]['op'] != "-":
+			items = [dict(items[0], op="-")] + list(items[1:])
 		dt = _lib.dtype_code(out.dtype)
 		n, q = a.shape[0], b.shape[0]
 		launches = self._plan(items)
