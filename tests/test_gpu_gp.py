@@ -523,12 +523,39 @@ def test_optimize_params_bandwidth(S):
 		t = torch.tensor(v, dtype=torch.float64, requires_grad=True)
 		f = _torch_lml(x, y, 0.1, 1.0, "se", t, 1.0)
 		f.backward()
-		return float(f), t.grad.numpy()
+		return float(f.detach()), t.grad.numpy()
 	ref = scipy.optimize.minimize(fun, np.array([0.3]), jac=True, method='L-BFGS-B', options={'gtol': 1e-4, 'ftol': 1e-12})
 	assert abs(abs(g_opt) - abs(ref.x[0])) / abs(ref.x[0]) < 1e-4
 	assert abs(f1 - ref.fun) / abs(ref.fun) < 1e-8
 	mu, std = GP.mean_std(x[:10])
 	assert mu.shape == (10, 1) and not bool(torch.isnan(std).any())
+
+
+def test_optimize_params_additive_sum(S):
+	"""bandwidth search over a SUM of two kernels on different coordinates (the additive models of mkl_estimator.py)"""
+	import scipy.optimize
+	rng = np.random.RandomState(9)
+	n, d = 220, 2
+	x = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)))
+	y = torch.sin(4 * x[:, :1]) + 0.5 * x[:, 1:2] ** 2 + 0.1 * torch.from_numpy(rng.normal(size=(n, 1)))
+	KF = S.KernelFunction
+	k = KF(kernel_name="squared_exponential", gamma=0.5, kappa=1.0, d=d, group=[0]) + KF(kernel_name="squared_exponential", gamma=0.5, kappa=1.0, d=d, group=[1])
+	GP = S.GaussianProcess(s=0.1, kernel=k, d=d)
+	GP.fit_gp(x, y)
+	f0 = lml(GP)
+	GP.optimize_params(type="bandwidth", restarts=1, optimizer="pytorch-minimize", init_func=lambda dim: np.full(dim, 0.5), maxiter=300)
+	g = [abs(float(GP.kernel_object.params_dict[key]['gamma'].reshape(-1)[0])) for key in ('0', '1')]
+	f1 = lml(GP)
+	assert f1 < f0
+
+	def fun(v):
+		t = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+		f = _lml_of(_tk(x, "se", t[0], 1.0, [0]) + _tk(x, "se", t[1], 1.0, [1]), y, 0.1, 1.0)
+		f.backward()
+		return float(f.detach()), t.grad.numpy()
+	ref = scipy.optimize.minimize(fun, np.array([0.5, 0.5]), jac=True, method='L-BFGS-B', options={'gtol': 1e-4, 'ftol': 1e-12})
+	assert abs(f1 - ref.fun) / abs(ref.fun) < 1e-7
+	assert abs(g[0] - abs(ref.x[0])) / abs(ref.x[0]) < 1e-3 and abs(g[1] - abs(ref.x[1])) / abs(ref.x[1]) < 1e-3
 
 
 def test_G12_kernelized_features(S):
