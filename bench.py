@@ -181,7 +181,7 @@ def main():
 					   "parallelism": "single GPU" if world == 1 else "2-D block-cyclic over %d GPUs" % world},
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),
-			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_kernel<double,false>", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
+			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_dtv_kernel<SUB> (+ gemm_nt_kernel<double,...> for the ragged / fused-epilogue launches)" if world == 1 else "stpy::gemm_nt_dtv_kernel / gemm_nt_kernel<double>", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
 						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
 						 "traffic_note": "HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes of this command (profiles/), 2*FETCH_SIZE + WRITE_SIZE",
 						 "launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4), "busy_ms_per_step": round(ub.value / args.steps, 2),

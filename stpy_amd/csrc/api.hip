@@ -260,6 +260,7 @@ void stpy_tune(int key, int value)
 	if (key == 3) g_trsm_pass_depth = value > 0 ? value : 1024;
 	if (key == 4) g_trsm_wg_target = value > 0 ? value : 2048;
 	if (key == 5) g_trsm_right_looking = value;
+	if (key == 6) g_gemm_dtv = value;
 	if (key == 7) g_potrf_diag_first_below = value;
 }
 

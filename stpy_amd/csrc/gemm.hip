@@ -24,6 +24,7 @@
 // K tile (two 16-byte LDS reads for f64) and MFMA number s of the tile uses element s of every
 // lane: k-slots {s, 4+s, 8+s, 12+s}.  A and B use the same map, which is all that is required.
 #include "common.h"
+#include <type_traits>
 
 namespace stpy {
 
@@ -32,6 +33,8 @@ constexpr int BM = 128, BN = 128, NTHREADS = 256;
 // the LDS-DMA pieces and the swizzle
 template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof(T); };
 int g_gemm_stagger = 0;
+int g_gemm_dtv = 1;            // A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
+int g_gemm_dtv_min_k = 64;
 int g_gemm_exp = 0;        // timing experiments only (results are wrong when != 0)
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
 
@@ -539,6 +542,189 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// fp64 variant with the A operand DIRECT TO VGPR (aligned shapes, plain products): only B goes through
+// LDS (LDS-DMA, two swizzled stages as above); lane (r16, g) of wave (wm, wn) owns, for each of its four
+// 16-row tiles, the 32 bytes A[row][k0 + 4g .. 4g+3] of a K tile -- exactly the two fragments its MFMAs
+// consume -- and refills each fragment IN PLACE for the next K tile right after the last MFMA that reads
+// it has been issued.  Half the LDS traffic and half the DMA pieces per flop; the structure the vendor
+// library's kernel for these shapes uses (its name says MT128x128x16 ... DTVA1).
+// The A loads are inline asm and every wait is placed by hand: hipcc's vmcnt bookkeeping cannot see the
+// LDS-DMA pieces, so its own waits either drain them or sit in the wrong place.  In steady state the
+// issue order per tile is 4 DMA pieces, 4 first-half refills, 4 second-half refills; when block (h, tm)
+// starts, exactly 11 younger operations than the load of fa[tm][h] may still be in flight, and at the end
+// of a tile the DMA pieces are older than the 8 refills.  A wait is tied to the fragment it guards through
+// a "+v" operand, which keeps the MFMAs that read it behind the wait.
+// Measured (tools/dtv_probe.hip, the stand-alone prototype): K-loop slope 73.3 TFLOP/s against 69.1.
+// ------------------------------------------------------------------------------------------
+template <bool SUB>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_nt_dtv_kernel(GemmArgs<double> p)
+{
+	typedef double T;
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	constexpr int BK = 16;
+	// NB the look-ahead stream's diagonal-block kernel runs beside ONE workgroup of this kernel: two of its waves per
+	// SIMD must fit into the registers one workgroup frees (512 - 232 = 280), hence its 128-VGPR cap in potrf.hip --
+	// with 138 it waited 2.5 ms per launch for a CU to drain completely and the factorisation got slower
+	__shared__ __attribute__((aligned(16))) double smem[2 * BN * BK];      // 32 KiB: B only
+
+	const int b = blockIdx.x;
+	int S = (b & 7) + 8 * (b >> 9);
+	const int w = (b >> 3) & 63;
+	int split = 0;
+	if (p.ksplit > 1) {
+		split = __builtin_amdgcn_readfirstlane(S / p.nsuper);
+		S -= split * p.nsuper;
+		if (split >= p.ksplit) return;
+	} else if (S >= p.nsuper) return;
+	int si, sj;
+	if (p.tri) {
+		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
+		while ((si + 1) * (si + 2) / 2 <= S) ++si;
+		while (si * (si + 1) / 2 > S) --si;
+		sj = S - si * (si + 1) / 2;
+	} else {
+		si = S / p.nst_n;
+		sj = S - si * p.nst_n;
+	}
+	const int ti = __builtin_amdgcn_readfirstlane(si * p.st_m + w / p.st_n);
+	const int tj = __builtin_amdgcn_readfirstlane(sj * p.st_n + w % p.st_n);
+	if (ti >= p.tiles_m || tj >= p.tiles_n) return;
+	if (p.tri && tj > ti) return;
+	if (p.bc_nbt > 0) {
+		const int I = (ti / p.bc_nbt + p.bc_i0) * p.bc_pr + p.bc_myr;
+		const int J = (tj / p.bc_nbt + p.bc_j0) * p.bc_pc + p.bc_myc;
+		if (I < J) return;
+	}
+	const int row0 = ti * BM, col0 = tj * BN;
+	const int kbeg = p.kskip ? row0 : split * p.kchunk;
+	const int kend = p.ksplit > 1 ? min(p.k, kbeg + p.kchunk) : p.k;
+	const int KT = (kend - kbeg) / BK;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
+
+	// ---- B through LDS-DMA: wave w moves rows [32w, 32w+32), 8 rows (1 KiB) per piece
+	const T* dsrc[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int r = wave * 32 + i * 8 + (lane >> 3);
+		const int f = (((r >> 1) & 3) << 1) | ((r >> 3) & 1);
+		dsrc[i] = p.B + (int64_t)(col0 + r) * p.ldb + kbeg + ((lane & 7) ^ f) * 2;
+	}
+	auto dma_one = [&](const T* gsrc, unsigned laddr) {
+		unsigned keep;
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep) : "v"(gsrc), "s"(laddr) : "memory");
+	};
+	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
+	auto dma_tile = [&](int buf, int k0) {
+		const unsigned base = lds0 + (unsigned)(buf * BN + wave * 32) * (BK * 8);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) dma_one(dsrc[i] + k0, base + i * 8 * BK * 8);
+	};
+
+	// ---- A straight into registers: uniform row-tile base + one 32-bit lane offset
+	const T* const abase = p.A + (int64_t)(row0 + wm * 64) * p.lda + kbeg;
+	const unsigned alane = (unsigned)r16 * (unsigned)p.lda + (unsigned)g * 4;       // elements
+	d2 fa[4][2];
+	auto lda_frag = [&](int tm, int h, int k0) {
+		const T* ptr = abase + (int64_t)tm * 16 * p.lda + (alane + (unsigned)k0 + (unsigned)h * 2);
+		asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[tm][h]) : "v"(ptr) : "memory");
+	};
+	auto wait_frag = [&](int tm, int h) { asm volatile("s_waitcnt vmcnt(11)" : "+v"(fa[tm][h]) :: "memory"); };
+
+	// ---- prologue: tile 0's B pieces and A fragments first, the C tile behind them (its latency overlaps theirs), then ONE
+	// ---- wait that hipcc can see (a builtin, not asm): otherwise it parks its vmcnt waits for the C loads at their first
+	// ---- use -- inside the loop, where they would drain the hand-counted queue every iteration
+	dma_tile(0, 0);
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm) lda_frag(tm, 0, 0);
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm) lda_frag(tm, 1, 0);
+	// accumulators: the C tile itself when subtracting (loaded straight into the accumulator registers; the B
+	// fragments are negated after their LDS read, so the product comes out as C - A B^T and the epilogue is store-only)
+	v4 acc[4][4];
+	T* const ctile = p.C + (int64_t)split * p.split_stride + (int64_t)row0 * p.ldc + col0;
+	const unsigned ldc32 = (unsigned)p.ldc;
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const T* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + MM::crow(lane, i)) * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = SUB ? crow[tn * 16] : T(0);
+		}
+	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+	__syncthreads();
+
+	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);
+	const int boff = (wn * 64 + r16) * BK;
+	int buf = 0;
+	// one K tile; LAST: nothing is prefetched any more, so the waits count down what is still in flight
+	auto tile = [&](auto last_tag, int knext) {
+		constexpr bool LAST = decltype(last_tag)::value;
+		if (!LAST) dma_tile(buf ^ 1, knext);
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			if (h == 1) __builtin_amdgcn_sched_barrier(0);
+			d2 fb[4];
+			const T* bs = smem + buf * BN * BK + boff + ((2 * g + h) ^ fsw) * 2;
+#pragma unroll
+			for (int t = 0; t < 4; ++t) { fb[t] = *(const d2*)(bs + t * 16 * BK); if (SUB) fb[t] = -fb[t]; }
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm) {
+				if (!LAST) wait_frag(tm, h);
+				else {      // younger loads than fa[tm][h]: the rest of its half, plus the whole second half while in the first
+					if (h == 0) { if (tm == 0) asm volatile("s_waitcnt vmcnt(7)" : "+v"(fa[tm][h]) :: "memory"); else if (tm == 1) asm volatile("s_waitcnt vmcnt(6)" : "+v"(fa[tm][h]) :: "memory");
+					              else if (tm == 2) asm volatile("s_waitcnt vmcnt(5)" : "+v"(fa[tm][h]) :: "memory"); else asm volatile("s_waitcnt vmcnt(4)" : "+v"(fa[tm][h]) :: "memory"); }
+					else { if (tm == 0) asm volatile("s_waitcnt vmcnt(3)" : "+v"(fa[tm][h]) :: "memory"); else if (tm == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(fa[tm][h]) :: "memory");
+					       else if (tm == 2) asm volatile("s_waitcnt vmcnt(1)" : "+v"(fa[tm][h]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[tm][h]) :: "memory"); }
+				}
+#pragma unroll
+				for (int s = 0; s < 2; ++s)
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn)
+						acc[tm][tn] = MM::mma(fa[tm][h][s], fb[tn][s], acc[tm][tn]);
+				if (!LAST) lda_frag(tm, h, knext);            // refill in place: every MFMA that reads fa[tm][h] has been issued
+			}
+		}
+		if (!LAST) {
+			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the four DMA pieces are older than the eight A refills
+			__syncthreads();
+			buf ^= 1;
+		}
+	};
+	for (int kt = 0; kt + 1 < KT; ++kt) tile(std::false_type{}, (kt + 1) * BK);
+	tile(std::true_type{}, 0);
+	// C may alias A (the block solve multiplies a row block by an inverse diagonal block in place): every wave of the
+	// workgroup has its last A fragments in registers (vmcnt(0) above) before anyone stores
+	__syncthreads();
+
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			T* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + MM::crow(lane, i)) * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) crow[tn * 16] = acc[tm][tn][i];
+		}
+	if (p.C2) {
+		T* const c2tile = p.C2 + (int64_t)row0 * p.ldc2 + col0;
+		const unsigned ldc2_32 = (unsigned)p.ldc2;
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				T* const c2row = c2tile + ((unsigned)(wm * 64 + tm * 16 + MM::crow(lane, i)) * ldc2_32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) c2row[tn * 16] = acc[tm][tn][i];
+			}
+	}
+}
+
 // ---- C (=, -=) sum over the split-K partial products (fixed order: the result does not depend on scheduling)
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -706,6 +892,19 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
+	if constexpr (sizeof(T) == 8) {
+		const int64_t dtv_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n * p.ksplit;
+		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && k >= g_gemm_dtv_min_k) {
+			if (mode == 1 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<true>), grid, block, 0, st, p);
+			else hipLaunchKernelGGL((gemm_nt_dtv_kernel<false>), grid, block, 0, st, p);
+			if (p.ksplit > 1) {
+				const int64_t total = m * n;
+				hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+				                   (const T*)split_work, p.ksplit, m, n, C, ldc, mode);
+			}
+			return check_launch("gemm_nt");
+		}
+	}
 	if (p.ksplit > 1) {
 		if (aligned) STPY_LAUNCH(false, false, 0); else STPY_LAUNCH(true, false, 0);
 		const int64_t total = m * n;

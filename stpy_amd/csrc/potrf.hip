@@ -174,8 +174,11 @@ __device__ __forceinline__ float bcast(float v, int src)
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// (VGPR cap: the kernel runs beside ONE trailing-update workgroup; two of its waves per SIMD must fit into the
+// registers one such workgroup frees -- 512 - 232 = 280 next to the direct-to-VGPR GEMM, i.e. at most 136 each;
+// the second argument of __launch_bounds__ is how that cap is expressed: four waves per SIMD = 128 VGPRs)
 template <typename T>
-__global__ __launch_bounds__(PT_THREADS)
+__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
                              T* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
 {
@@ -304,7 +307,7 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 			// of k-step s, so the blocks W_kj this wave has produced stay in registers and feed the next products
 			// directly -- no trip through memory between the steps of the chain.  Loops are indexed relative to j so
 			// that every register array index is a compile-time constant.
-			v4 wcol[NSB];
+			v4 wcol[NSB - 1];        // wcol[kk - 1] = W_{j+kk, j}
 #pragma unroll
 			for (int ii = 1; ii < NSB; ++ii) {
 				const int i = j + ii;
@@ -316,14 +319,14 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 #pragma unroll
 						for (int s4 = 0; s4 < 4; ++s4) {
 							const T a = S[tri(i * SB + r16, k * SB + 4 * s4 + g)];                      // L_ik[r16][kk]
-							const T b = (kk == 0) ? WD[(j * SB + 4 * s4 + g) * WLD + r16] : wcol[kk][s4];    // W_kj[kk][c]
+							const T b = (kk == 0) ? WD[(j * SB + 4 * s4 + g) * WLD + r16] : wcol[kk - 1][s4];    // W_kj[kk][c]
 							t = MM::mma(a, b, t);
 						}
 					}
 					v4 w = v4{0, 0, 0, 0};
 #pragma unroll
 					for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], t[s4], w);
-					wcol[ii] = w;
+					wcol[ii - 1] = w;
 #pragma unroll
 					for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
 				}

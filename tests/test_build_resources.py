@@ -55,7 +55,7 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 	seen = 0
 	for b in blocks:
 		name = b.split()[0]
-		if "gemm_nt_kernel" not in name and "potf2_trtri_mfma_kernel" not in name:
+		if "gemm_nt_kernel" not in name and "potf2_trtri_mfma_kernel" not in name and "gemm_nt_dtv_kernel" not in name:
 			continue
 		seen += 1
 		scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
@@ -70,6 +70,13 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 			else:
 				assert scratch < 400, (name, scratch, vspill)
 			assert vgprs <= 256
-		else:
+		elif "gemm_nt_dtv_kernel" in name:
+			# direct-to-VGPR GEMM: a spill there also means hipcc reloads before the loop and waits for them inside it,
+			# which drains the hand-counted load queue
 			assert vspill == 0 and scratch == 0, (name, scratch, vspill)
+			assert vgprs <= 232          # 512 - 232 = 280 registers per SIMD must stay for the diagonal-block kernel's two waves
+		else:
+			# diagonal-block kernel: capped at 128 VGPRs so that it fits beside one GEMM workgroup (see gemm.hip); a few
+			# loop-invariant addresses may go to scratch, the row / accumulator arrays may not
+			assert vgprs <= 136 and scratch <= 64, (name, vgprs, scratch, vspill)
 	assert seen >= 2

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <vector>
+#include <type_traits>
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -20,7 +21,7 @@ struct Args { const double* A; const double* B; double* C; long lda, ldb, ldc; i
 // A[row][k0 + 4g .. 4g+3] of a K tile -- exactly the two d2 fragments (halves h = 0, 1) its MFMAs consume -- and
 // refills each fragment IN PLACE for the next K tile right after the last MFMA that reads it has been issued.
 // B: LDS-DMA into two swizzled stages as in gemm_nt_kernel (half the LDS traffic, half the DMA instructions).
-template <bool SUB>
+template <bool SUB, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void dtv_gemm(Args p)
 {
 	__shared__ __attribute__((aligned(16))) double smem[2 * TN * BK];      // 32 KiB
@@ -60,11 +61,24 @@ __global__ __launch_bounds__(256, 2) void dtv_gemm(Args p)
 	const double* const abase = p.A + (long)(row0 + wm * 64) * p.lda;
 	const unsigned alane = (unsigned)r16 * (unsigned)p.lda + (unsigned)g * 4;       // elements
 	d2 fa[4][2];
+	// asm loads: hipcc's own vmcnt bookkeeping cannot see the LDS-DMA pieces, so the waits are placed by hand.  A wait is
+	// tied to the fragment it guards through a "+v" operand, which keeps the MFMAs that read it behind the wait.
 	auto lda_frag = [&](int tm, int h, int k0) {
-		fa[tm][h] = *(const d2*)(abase + (long)tm * 16 * p.lda + (alane + (unsigned)k0 + (unsigned)h * 2));
+		const double* ptr = abase + (long)tm * 16 * p.lda + (alane + (unsigned)k0 + (unsigned)h * 2);
+		asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[tm][h]) : "v"(ptr) : "memory");
 	};
-
+	// steady state, in issue order per tile: 4 DMA pieces, 4 first-half refills, 4 second-half refills.  When block
+	// (h, tm) starts, exactly 11 younger operations than the load of fa[tm][h] may still be in flight.
+	auto wait_frag = [&](int tm, int h) { asm volatile("s_waitcnt vmcnt(11)" : "+v"(fa[tm][h]) :: "memory"); };
 	const int KT = p.k / BK;
+	// prologue: tile 0's B pieces and A fragments first, the C tile behind them (so its latency overlaps theirs), then ONE
+	// wait for everything that hipcc can see (a builtin, not asm): otherwise it parks its vmcnt waits for the C loads at their
+	// first use -- inside the loop, where they would drain the hand-counted queue every iteration
+	dma_tile(0, 0);
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm) lda_frag(tm, 0, 0);
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm) lda_frag(tm, 1, 0);
 	d4 acc[4][4];
 	double* const ctile = p.C + (long)row0 * p.ldc + col0;
 #pragma unroll
@@ -75,18 +89,16 @@ __global__ __launch_bounds__(256, 2) void dtv_gemm(Args p)
 #pragma unroll
 			for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = SUB ? crow[tn * 16] : 0.0;
 		}
-#pragma unroll
-	for (int tm = 0; tm < 4; ++tm) { lda_frag(tm, 0, 0); lda_frag(tm, 1, 0); }
-	dma_tile(0, 0);
 	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
 	__syncthreads();
 
 	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);
 	const int boff = (wn * 64 + r16) * BK;
 	int buf = 0;
-	for (int kt = 0; kt < KT; ++kt) {
-		const int knext = (kt + 1 < KT ? kt + 1 : kt) * BK;        // past the end: harmless re-load of the last tile
-		dma_tile(buf ^ 1, knext);
+	// one K tile; LAST: nothing is prefetched any more, so the waits count down what is still in flight
+	auto tile = [&](auto last_tag, int knext) {
+		constexpr bool LAST = decltype(last_tag)::value;
+		if (!LAST) dma_tile(buf ^ 1, knext);
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			if (h == 1) __builtin_amdgcn_sched_barrier(0);
@@ -96,18 +108,29 @@ __global__ __launch_bounds__(256, 2) void dtv_gemm(Args p)
 			for (int t = 0; t < 4; ++t) { fb[t] = *(const d2*)(bs + t * 16 * BK); if (SUB) fb[t] = -fb[t]; }      // C - A B^T: negate the operand that is waited for anyway
 #pragma unroll
 			for (int tm = 0; tm < 4; ++tm) {
+				if (!LAST) wait_frag(tm, h);
+				else {      // younger loads than fa[tm][h]: the rest of its half, plus the whole second half while in the first
+					if (h == 0) { if (tm == 0) asm volatile("s_waitcnt vmcnt(7)" : "+v"(fa[tm][h]) :: "memory"); else if (tm == 1) asm volatile("s_waitcnt vmcnt(6)" : "+v"(fa[tm][h]) :: "memory");
+					              else if (tm == 2) asm volatile("s_waitcnt vmcnt(5)" : "+v"(fa[tm][h]) :: "memory"); else asm volatile("s_waitcnt vmcnt(4)" : "+v"(fa[tm][h]) :: "memory"); }
+					else { if (tm == 0) asm volatile("s_waitcnt vmcnt(3)" : "+v"(fa[tm][h]) :: "memory"); else if (tm == 1) asm volatile("s_waitcnt vmcnt(2)" : "+v"(fa[tm][h]) :: "memory");
+					       else if (tm == 2) asm volatile("s_waitcnt vmcnt(1)" : "+v"(fa[tm][h]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[tm][h]) :: "memory"); }
+				}
 #pragma unroll
 				for (int s = 0; s < 2; ++s)
 #pragma unroll
 					for (int tn = 0; tn < 4; ++tn)
 						acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[tm][h][s], fb[tn][s], acc[tm][tn], 0, 0, 0);
-				lda_frag(tm, h, knext);            // refill in place: every MFMA that reads fa[tm][h] has been issued
+				if (!LAST) lda_frag(tm, h, knext);            // refill in place: every MFMA that reads fa[tm][h] has been issued
 			}
 		}
-		asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the four DMA pieces are older than the eight A refills
-		__syncthreads();
-		buf ^= 1;
-	}
+		if (!LAST) {
+			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the four DMA pieces are older than the eight A refills
+			__syncthreads();
+			buf ^= 1;
+		}
+	};
+	for (int kt = 0; kt + 1 < KT; ++kt) tile(std::false_type{}, (kt + 1) * BK);
+	tile(std::true_type{}, 0);
 #pragma unroll
 	for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -125,6 +148,7 @@ __global__ void fill_kernel(double* x, size_t n, unsigned seed)
 	for (; i < n; i += stride) { unsigned h = (unsigned)(i * 2654435761u) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; x[i] = (int)(h >> 8) * (1.0 / (1 << 24)) - 0.5; }
 }
 
+static int g_var = 0;
 static void launch(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int m, int n, int k, int sub)
 {
 	Args p{A, B, C, lda, ldb, ldc, m, n, k, sub, m / TM, n / TN, 0, 0};
@@ -132,8 +156,11 @@ static void launch(const double* A, long lda, const double* B, long ldb, double*
 	p.nst_n = (p.tiles_n + 7) / 8;
 	p.nsuper = nst_m * p.nst_n;
 	const int blocks = ((p.nsuper + 7) / 8) * 512;
-	if (sub) hipLaunchKernelGGL(dtv_gemm<true>, dim3(blocks), dim3(256), 0, 0, p);
-	else hipLaunchKernelGGL(dtv_gemm<false>, dim3(blocks), dim3(256), 0, 0, p);
+	if (!sub) hipLaunchKernelGGL((dtv_gemm<false, 0>), dim3(blocks), dim3(256), 0, 0, p);
+	else if (g_var == 0) hipLaunchKernelGGL((dtv_gemm<true, 0>), dim3(blocks), dim3(256), 0, 0, p);
+	else if (g_var == 1) hipLaunchKernelGGL((dtv_gemm<true, 1>), dim3(blocks), dim3(256), 0, 0, p);
+	else if (g_var == 2) hipLaunchKernelGGL((dtv_gemm<true, 2>), dim3(blocks), dim3(256), 0, 0, p);
+	else hipLaunchKernelGGL((dtv_gemm<true, 3>), dim3(blocks), dim3(256), 0, 0, p);
 }
 
 int main()
@@ -166,8 +193,10 @@ int main()
 		}
 	}
 	// ---- timing on the trailing-update shape (full rectangle)
-	const int shapes[][3] = {{32768, 32768, 1024}, {32768, 32768, 4096}, {32768, 1024, 32768}, {16384, 16384, 512}};
+	const int shapes[][3] = {{32768, 32768, 1024}, {32768, 32768, 4096}};
+	for (int var = 0; var < 4; ++var)
 	for (auto& sh : shapes) {
+		g_var = var;
 		const int m = sh[0], n = sh[1], k = sh[2];
 		double *dA, *dB, *dC;
 		hipMalloc(&dA, (size_t)m * k * 8); hipMalloc(&dB, (size_t)n * k * 8); hipMalloc(&dC, (size_t)m * n * 8);
@@ -183,7 +212,7 @@ int main()
 			float ms; hipEventElapsedTime(&ms, e0, e1);
 			best = fminf(best, ms);
 		}
-		printf("dtv m=%d n=%d k=%d: %.3f ms  %.2f TFLOP/s\n", m, n, k, best, 2.0 * m * n * k / best / 1e9);
+		printf("dtv var=%d m=%d n=%d k=%d: %.3f ms  %.2f TFLOP/s\n", g_var, m, n, k, best, 2.0 * m * n * k / best / 1e9);
 		hipFree(dA); hipFree(dB); hipFree(dC);
 	}
 	return 0;

@@ -182,6 +182,28 @@ def leftlook():
 
 if __name__ == "__main__":
 	which = sys.argv[1] if len(sys.argv) > 1 else "all"
+	if which == "dtv":
+		# A/B of the direct-to-VGPR GEMM (stpy_tune key 6) on GEMM shapes, then on the whole step
+		n = 32768
+		C0 = torch.randn(n, n, dtype=torch.float64, device=dev)
+		for k in (256, 1024, 4096):
+			P = torch.randn(n, k, dtype=torch.float64, device=dev)
+			outs = {}
+			for rnd in range(2):
+				for v in (0, 1):
+					lib.stpy_tune(6, v)
+					C = C0.clone()
+					f = lambda: L.check(lib.stpy_gemm_nt(L.F64, n, n, k, L.ptr(P), k, L.ptr(P), k, L.ptr(C), n, 1, 1, L.stream_ptr()), "gemm")
+					f(); torch.cuda.synchronize()
+					outs[v] = C[:2048, :2048].clone()
+					t = timeit(f, reps=3, warm=0)[0]
+					print("tri update n=%d k=%d dtv=%d: %.3f ms  %.2f TF" % (n, k, v, t * 1e3, float(n) * (n + 128) * k / t / 1e12), flush=True)
+			print("  max |diff| %.2e" % float((outs[0] - outs[1]).abs().max()), flush=True)
+			del P
+		del C0
+		torch.cuda.empty_cache()
+		ab_fit(6, [0, 1, 1024, 8192])
+		lib.stpy_tune(6, 1024)
 	if which == "diagfirst":
 		for n in (8192, 16384, 32768, 65536):
 			for thr in (1, 1 << 30, 1, 1 << 30):
