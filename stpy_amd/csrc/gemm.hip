@@ -543,9 +543,9 @@ void gemm_nt_kernel(GemmArgs<T> p)
 }
 
 // ------------------------------------------------------------------------------------------
-// fp64 variant with the A operand DIRECT TO VGPR (aligned shapes, plain products): only B goes through
+// Variant with the A operand DIRECT TO VGPR (aligned shapes, plain products, both types): only B goes through
 // LDS (LDS-DMA, two swizzled stages as above); lane (r16, g) of wave (wm, wn) owns, for each of its four
-// 16-row tiles, the 32 bytes A[row][k0 + 4g .. 4g+3] of a K tile -- exactly the two fragments its MFMAs
+// 16-row tiles, the 32 bytes (chunks 2g, 2g+1) of a 128-byte K-tile row -- exactly the two fragments its MFMAs
 // consume -- and refills each fragment IN PLACE for the next K tile right after the last MFMA that reads
 // it has been issued.  Half the LDS traffic and half the DMA pieces per flop; the structure the vendor
 // library's kernel for these shapes uses (its name says MT128x128x16 ... DTVA1).
@@ -557,19 +557,19 @@ void gemm_nt_kernel(GemmArgs<T> p)
 // a "+v" operand, which keeps the MFMAs that read it behind the wait.
 // Measured (tools/dtv_probe.hip, the stand-alone prototype): K-loop slope 73.3 TFLOP/s against 69.1.
 // ------------------------------------------------------------------------------------------
-template <bool SUB>
+template <typename T, bool SUB>
 __global__ __launch_bounds__(NTHREADS, 2)
-void gemm_nt_dtv_kernel(GemmArgs<double> p)
+void gemm_nt_dtv_kernel(GemmArgs<T> p)
 {
-	typedef double T;
-	typedef Mfma<double> MM;
-	typedef MM::v4 v4;
-	typedef double d2 __attribute__((ext_vector_type(2)));
-	constexpr int BK = 16;
+	typedef Mfma<T> MM;
+	typedef typename MM::v4 v4;
+	constexpr int CH = 16 / sizeof(T);                 // elements per 16-byte chunk (2 doubles / 4 floats): one MFMA k-step each
+	typedef T d2 __attribute__((ext_vector_type(CH)));     // one chunk = one fragment
+	constexpr int BK = KTile<T>::BK;
 	// NB the look-ahead stream's diagonal-block kernel runs beside ONE workgroup of this kernel: two of its waves per
 	// SIMD must fit into the registers one workgroup frees (512 - 232 = 280), hence its 128-VGPR cap in potrf.hip --
 	// with 138 it waited 2.5 ms per launch for a CU to drain completely and the factorisation got slower
-	__shared__ __attribute__((aligned(16))) double smem[2 * BN * BK];      // 32 KiB: B only
+	__shared__ __attribute__((aligned(16))) T smem[2 * BN * BK];      // 32 KiB: B only
 
 	const int b = blockIdx.x;
 	int S = (b & 7) + 8 * (b >> 9);
@@ -612,7 +612,7 @@ void gemm_nt_dtv_kernel(GemmArgs<double> p)
 	for (int i = 0; i < 4; ++i) {
 		const int r = wave * 32 + i * 8 + (lane >> 3);
 		const int f = (((r >> 1) & 3) << 1) | ((r >> 3) & 1);
-		dsrc[i] = p.B + (int64_t)(col0 + r) * p.ldb + kbeg + ((lane & 7) ^ f) * 2;
+		dsrc[i] = p.B + (int64_t)(col0 + r) * p.ldb + kbeg + ((lane & 7) ^ f) * CH;
 	}
 	auto dma_one = [&](const T* gsrc, unsigned laddr) {
 		unsigned keep;
@@ -621,17 +621,17 @@ void gemm_nt_dtv_kernel(GemmArgs<double> p)
 	};
 	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
 	auto dma_tile = [&](int buf, int k0) {
-		const unsigned base = lds0 + (unsigned)(buf * BN + wave * 32) * (BK * 8);
+		const unsigned base = lds0 + (unsigned)(buf * BN + wave * 32) * 128u;       // 128-byte rows
 #pragma unroll
-		for (int i = 0; i < 4; ++i) dma_one(dsrc[i] + k0, base + i * 8 * BK * 8);
+		for (int i = 0; i < 4; ++i) dma_one(dsrc[i] + k0, base + i * 8 * 128u);
 	};
 
 	// ---- A straight into registers: uniform row-tile base + one 32-bit lane offset
 	const T* const abase = p.A + (int64_t)(row0 + wm * 64) * p.lda + kbeg;
-	const unsigned alane = (unsigned)r16 * (unsigned)p.lda + (unsigned)g * 4;       // elements
+	const unsigned alane = (unsigned)r16 * (unsigned)p.lda + (unsigned)g * 2 * CH;  // elements: chunk 2g of the row
 	d2 fa[4][2];
 	auto lda_frag = [&](int tm, int h, int k0) {
-		const T* ptr = abase + (int64_t)tm * 16 * p.lda + (alane + (unsigned)k0 + (unsigned)h * 2);
+		const T* ptr = abase + (int64_t)tm * 16 * p.lda + (alane + (unsigned)k0 + (unsigned)h * CH);
 		asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[tm][h]) : "v"(ptr) : "memory");
 	};
 	auto wait_frag = [&](int tm, int h) { asm volatile("s_waitcnt vmcnt(11)" : "+v"(fa[tm][h]) :: "memory"); };
@@ -671,7 +671,7 @@ void gemm_nt_dtv_kernel(GemmArgs<double> p)
 		for (int h = 0; h < 2; ++h) {
 			if (h == 1) __builtin_amdgcn_sched_barrier(0);
 			d2 fb[4];
-			const T* bs = smem + buf * BN * BK + boff + ((2 * g + h) ^ fsw) * 2;
+			const T* bs = smem + buf * BN * BK + boff + ((2 * g + h) ^ fsw) * CH;
 #pragma unroll
 			for (int t = 0; t < 4; ++t) { fb[t] = *(const d2*)(bs + t * 16 * BK); if (SUB) fb[t] = -fb[t]; }
 #pragma unroll
@@ -684,7 +684,7 @@ void gemm_nt_dtv_kernel(GemmArgs<double> p)
 					       else if (tm == 2) asm volatile("s_waitcnt vmcnt(1)" : "+v"(fa[tm][h]) :: "memory"); else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fa[tm][h]) :: "memory"); }
 				}
 #pragma unroll
-				for (int s = 0; s < 2; ++s)
+				for (int s = 0; s < CH; ++s)
 #pragma unroll
 					for (int tn = 0; tn < 4; ++tn)
 						acc[tm][tn] = MM::mma(fa[tm][h][s], fb[tn][s], acc[tm][tn]);
@@ -892,11 +892,11 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
-	if constexpr (sizeof(T) == 8) {
+	{
 		const int64_t dtv_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n * p.ksplit;
-		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && k >= g_gemm_dtv_min_k) {
-			if (mode == 1 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<true>), grid, block, 0, st, p);
-			else hipLaunchKernelGGL((gemm_nt_dtv_kernel<false>), grid, block, 0, st, p);
+		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && k >= g_gemm_dtv_min_k * (int)(8 / sizeof(T))) {
+			if (mode == 1 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, true>), grid, block, 0, st, p);
+			else hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, false>), grid, block, 0, st, p);
 			if (p.ksplit > 1) {
 				const int64_t total = m * n;
 				hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
