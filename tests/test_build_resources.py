@@ -80,3 +80,21 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 			# loop-invariant addresses may go to scratch, the row / accumulator arrays may not
 			assert vgprs <= 136 and scratch <= 64, (name, vgprs, scratch, vspill)
 	assert seen >= 2
+
+
+def test_dtv_kernel_fragments_are_not_copied(tmp_path):
+	"""gemm_nt_dtv_kernel loads A fragments with inline asm and guards them with hand-counted waits.  The compiler believes
+	the asm's output is valid at once; if it ever copied a fragment register between the load and its wait, the copy
+	would read stale data.  The subtracting instantiations contain no other reason for a register move inside the MFMA
+	range (the overwriting ones zero their accumulators there), so: none at all."""
+	asm = tmp_path / "gemm.s"
+	subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-S", "--cuda-device-only",
+					os.path.join(CSRC, "gemm.hip"), "-o", str(asm)], capture_output=True, text=True, check=True)
+	src = asm.read_text()
+	names = [n for n in re.findall(r"^(_ZN4stpy18gemm_nt_dtv_kernel\w+):", src, re.M) if "Lb1EEEv" in n]
+	assert len(names) == 2
+	for name in names:
+		body = src[src.index(name + ":"):].split(".Lfunc_end")[0].split("\n")
+		mf = [k for k, l in enumerate(body) if "v_mfma" in l]
+		moves = [l.strip() for l in body[mf[0]:mf[-1]] if re.match(r"\s*v_(mov|accvgpr|pk_mov)", l)]
+		assert not moves, (name, moves[:4])
