@@ -262,6 +262,7 @@ void stpy_tune(int key, int value)
 	if (key == 5) g_trsm_right_looking = value;
 	if (key == 6) g_gemm_dtv = value;
 	if (key == 7) g_potrf_diag_first_below = value;
+	if (key == 8) g_gemm_k128 = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */

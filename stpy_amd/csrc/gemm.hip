@@ -35,6 +35,7 @@ template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof
 int g_gemm_stagger = 0;
 int g_gemm_dtv = 1;            // A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
 int g_gemm_dtv_min_k = 64;
+int g_gemm_k128 = 768;           // K = 128 products with at most this many 64 x 64 tiles take the one-volley kernel (stpy_tune key 8; 0 = never)
 int g_gemm_exp = 0;        // timing experiments only (results are wrong when != 0)
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
 
@@ -725,6 +726,104 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// K = 128 products on small grids (the panel chain of the factorisation and of the block solve: a row block
+// times an inverse diagonal block, C may alias A).  Through the kernels above such a launch is a chain of eight
+// K tiles on a few dozen workgroups, each tile waiting a full memory latency with nothing to hide it: 45-90 us
+// for ~3 us of MFMA work.  Here a workgroup owns 64 rows x 128 columns: it loads ALL of its A rows and half of its B rows
+// (64 x 128 each, 128 KiB of LDS) in one volley of LDS-DMA rows, waits once, multiplies from LDS, and repeats with the
+// second half of B.  One workgroup per row block covers the full width, so an in-place product (n = 128) is safe.  Rows are 1 KiB; the XOR swizzle of the
+// 128-byte layout is applied to the low three bits of the chunk index, which keeps ds_read_b128 conflict-free.
+// ------------------------------------------------------------------------------------------
+template <bool SUB>
+__global__ __launch_bounds__(NTHREADS, 1)
+void gemm_nt_k128_kernel(GemmArgs<double> p)
+{
+	typedef double T;
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	constexpr int TM = 64, TH = 64, K = 128;           // a workgroup owns 64 rows x 128 columns, as two 64-column halves
+	__shared__ __attribute__((aligned(16))) double smem[(TM + TH) * K];       // 128 KiB: the A rows + one half of the B rows
+	const int ti = blockIdx.x, tj = blockIdx.y;
+	const int row0 = ti * TM, col0 = tj * 2 * TH;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
+
+	// ---- one LDS-DMA instruction per 1 KiB row: wave w moves rows [16w, 16w+16) of A / of the current half of B
+	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
+	auto dma_row = [&](const T* g, unsigned laddr) {
+		unsigned keep;
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep) : "v"(g), "s"(laddr) : "memory");
+	};
+	auto load_rows = [&](const T* base, int64_t ld, int first_row, int row_limit, int lds_row0) {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int r = wave * 16 + i;
+			const int f = (((r >> 1) & 3) << 1) | ((r >> 3) & 1);
+			const int c = (lane & ~7) | ((lane & 7) ^ f);            // source chunk that lands at physical chunk `lane`
+			dma_row(base + (int64_t)min(first_row + r, row_limit) * ld + c * 2, lds0 + (unsigned)(lds_row0 + r) * 1024u);
+		}
+	};
+	load_rows(p.A, p.lda, row0, p.m - 1, 0);
+	load_rows(p.B, p.ldb, col0, p.n - 1, TM);
+
+	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);
+	const T* as = smem + (wm * 32 + r16) * K;
+	const T* bs = smem + (TM + wn * 32 + r16) * K;
+	v4 acc[2][2][2];                                   // [half][tm][tn]
+#pragma unroll
+	for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+		for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn) acc[hf][tm][tn] = v4{0, 0, 0, 0};
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+#pragma unroll
+		for (int kt = 0; kt < K / 16; ++kt)
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int off = (kt * 8 + ((2 * g + h) ^ fsw)) * 2;
+				d2 fa[2], fb[2];
+#pragma unroll
+				for (int t = 0; t < 2; ++t) { fa[t] = *(const d2*)(as + t * 16 * K + off); fb[t] = *(const d2*)(bs + t * 16 * K + off); }
+#pragma unroll
+				for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+					for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+						for (int tn = 0; tn < 2; ++tn) acc[hf][tm][tn] = MM::mma(fa[tm][s2], fb[tn][s2], acc[hf][tm][tn]);
+			}
+		if (hf == 0) {
+			__syncthreads();                               // every wave has finished reading the first half of B
+			load_rows(p.B, p.ldb, col0 + TH, p.n - 1, TM);
+		}
+	}
+	// every A row of this workgroup is in LDS (and consumed) before anything is stored: C may alias A
+
+	T* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
+	T* const c2tile = p.C2 ? p.C2 + (int64_t)row0 * p.ldc2 + col0 : nullptr;
+#pragma unroll
+	for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+		for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int lr = wm * 32 + tm * 16 + MM::crow(lane, i);
+				if (row0 + lr >= p.m) continue;
+#pragma unroll
+				for (int tn = 0; tn < 2; ++tn) {
+					const int lc = hf * TH + wn * 32 + tn * 16 + r16;
+					T* c = ctile + (int64_t)lr * p.ldc + lc;
+					const T v = SUB ? *c - acc[hf][tm][tn][i] : acc[hf][tm][tn][i];
+					*c = v;
+					if (c2tile) c2tile[(int64_t)lr * p.ldc2 + lc] = v;
+				}
+			}
+}
+
 // ---- C (=, -=) sum over the split-K partial products (fixed order: the result does not depend on scheduling)
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -892,6 +991,17 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
+	if constexpr (sizeof(T) == 8) {
+		// the panel chain's K = 128 products (see gemm_nt_k128_kernel)
+		const int64_t t64 = ((m + 63) / 64) * (n / 64);
+		if (g_gemm_k128 && k == 128 && (n % 128 == 0) && (mode == 0 || mode == 1) && !lower_only && !bc && p.ksplit == 1 && !g_gemm_exp &&
+		    t64 <= g_gemm_k128 && (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {
+			const dim3 g64((unsigned)((m + 63) / 64), (unsigned)(n / 128));
+			if (mode == 1) hipLaunchKernelGGL((gemm_nt_k128_kernel<true>), g64, block, 0, st, p);
+			else hipLaunchKernelGGL((gemm_nt_k128_kernel<false>), g64, block, 0, st, p);
+			return check_launch("gemm_nt");
+		}
+	}
 	{
 		const int64_t dtv_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n * p.ksplit;
 		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && k >= g_gemm_dtv_min_k * (int)(8 / sizeof(T))) {

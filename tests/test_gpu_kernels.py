@@ -84,6 +84,35 @@ def test_gemm_nt_splitk_plan(L):
 	assert b"workspace" in lib.stpy_last_error_string()
 
 
+@pytest.mark.parametrize("m,n,mode", [(300, 128, 0), (4096, 128, 1), (1000, 256, 1), (64, 128, 0), (129, 384, 0)])
+def test_gemm_nt_k128_small_grid(L, m, n, mode):
+	"""K = 128 on a small grid takes the one-volley kernel (panel chain); also in place, C aliasing A (n = k = 128)."""
+	rng = np.random.RandomState(m + n + mode)
+	k = 128
+	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+	Ad, Bd, Cd = dev(A), dev(B), dev(C)
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr()), "gemm")
+	ref = A @ B.T if mode == 0 else C - A @ B.T
+	assert rel_err(Cd.cpu().numpy(), ref) < 1e-13
+	# the same product with the kernel switched off gives the same numbers to rounding
+	lib.stpy_tune(8, 0)
+	try:
+		Cd2 = dev(C)
+		L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd2), n, mode, 0, L.stream_ptr()), "gemm")
+	finally:
+		lib.stpy_tune(8, 768)
+	assert rel_err(Cd2.cpu().numpy(), ref) < 1e-13
+	if n == 128 and mode == 0:        # in place: A <- A B^T inside a wider buffer (the block solve's multiply by an inverse block)
+		big = rng.normal(size=(m, 400))
+		bd = dev(big)
+		pa = ctypes.c_void_p(bd.data_ptr() + 128 * 8)
+		L.check(lib.stpy_gemm_nt(L.F64, m, 128, 128, pa, 400, L.ptr(Bd), k, pa, 400, 0, 0, L.stream_ptr()), "gemm")
+		out = bd.cpu().numpy()
+		assert rel_err(out[:, 128:256], big[:, 128:256] @ B.T) < 1e-13
+		assert np.array_equal(out[:, :128], big[:, :128]) and np.array_equal(out[:, 256:], big[:, 256:])
+
+
 def test_gemm_nt_asymmetric_layout(L):
 	"""A = I with an asymmetric B: catches a transposed C/D fragment map (cdna guide section 3)."""
 	n = 128
