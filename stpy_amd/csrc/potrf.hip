@@ -191,60 +191,96 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r16 = lane & 15, g = lane >> 4;
 
-	for (int idx = tid; idx < IB * IB; idx += PT_THREADS) {
-		const int i = idx >> 7, j = idx & 127;
-		if (j > i) continue;
-		T v = T(0);
-		if (i < nbk) v = A[(int64_t)i * lda + j];
-		else if (i == j) v = T(1);
-		S[tri(i, j)] = v;
+	// all 32 loads of a thread are issued before the first LDS store (one memory round trip instead of 32 in a chain:
+	// this phase took 9.8 us of the kernel's 87)
+	{
+		constexpr int NIT = IB * IB / PT_THREADS;
+		T v[NIT];
+#pragma unroll
+		for (int it = 0; it < NIT; ++it) {
+			const int idx = tid + it * PT_THREADS, i = idx >> 7, j = idx & 127;
+			v[it] = (j <= i && i < nbk) ? A[(int64_t)i * lda + j] : ((i == j) ? T(1) : T(0));
+		}
+#pragma unroll
+		for (int it = 0; it < NIT; ++it) {
+			const int idx = tid + it * PT_THREADS, i = idx >> 7, j = idx & 127;
+			if (j <= i) S[tri(i, j)] = v[it];
+		}
 	}
 	__syncthreads();
 
-	for (int kb = 0; kb < NSB; ++kb) {
+	// ---- 16x16 diagonal sub-block kb (ONE wave): factor + inverse, rows in registers (lane i < 16 holds row i)
+	auto diag_block = [&](int kb) {
 		const int o = kb * SB;
-		if (wave == 0) {
-			// ---- 16x16 diagonal sub-block: lane i (< 16) holds row i in registers
-			T r[SB];
+		T r[SB];
 #pragma unroll
-			for (int k = 0; k < SB; ++k) r[k] = (lane < SB && k <= lane) ? S[tri(o + lane, o + k)] : T(0);
-			T myrinv = T(1);
+		for (int k = 0; k < SB; ++k) r[k] = (lane < SB && k <= lane) ? S[tri(o + lane, o + k)] : T(0);
+		T myrinv = T(1);
 #pragma unroll
-			for (int j = 0; j < SB; ++j) {
-				T d = bcast(r[j], j);
-				if (!(d > T(0)) || !(d < T(1e300))) {
-					if (lane == 0) atomicCAS(info, 0, block_row0 + o + j + 1);
-					d = T(1);
-				}
-				const T l = sqrt(d), rl = T(1) / l;
-				r[j] = (lane == j) ? l : r[j] * rl;
-				if (lane == j) myrinv = rl;
-#pragma unroll
-				for (int k = j + 1; k < SB; ++k) {
-					const T lkj = bcast(r[j], k);
-					const T upd = r[k] - r[j] * lkj;
-					r[k] = (lane >= k) ? upd : r[k];
-				}
-				__builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of later pivots from being hoisted (register pressure)
+		for (int j = 0; j < SB; ++j) {
+			T d = bcast(r[j], j);
+			if (!(d > T(0)) || !(d < T(1e300))) {
+				if (lane == 0) atomicCAS(info, 0, block_row0 + o + j + 1);
+				d = T(1);
 			}
-			// ---- inverse of the 16x16 factor: lane c holds column c of W
-			T wc[SB];
+			// 1/sqrt(d) from the hardware estimate + two Newton steps, l = d * rl (no sqrt + division on the pivot chain)
+			T rl = (T)__builtin_amdgcn_rsq(d);
+			rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+			rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+			const T l = d * rl;
+			r[j] = (lane == j) ? l : r[j] * rl;
+			if (lane == j) myrinv = rl;
 #pragma unroll
-			for (int i = 0; i < SB; ++i) {
-				T acc = (lane == i) ? T(1) : T(0);
-#pragma unroll
-				for (int k = 0; k < i; ++k) acc -= bcast(r[k], i) * wc[k];
-				wc[i] = acc * bcast(myrinv, i);
-				__builtin_amdgcn_sched_barrier(0);
+			for (int k = j + 1; k < SB; ++k) {
+				const T lkj = bcast(r[j], k);
+				const T upd = r[k] - r[j] * lkj;
+				r[k] = (lane >= k) ? upd : r[k];
 			}
-			if (lane < SB) {
+			__builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of later pivots from being hoisted (register pressure)
+		}
+		// inverse of the 16x16 factor: lane c holds column c of W
+		T wc[SB];
 #pragma unroll
-				for (int k = 0; k < SB; ++k) {
-					if (k <= lane) S[tri(o + lane, o + k)] = r[k];
-					WD[(kb * SB + k) * WLD + lane] = wc[k];            // W[k][c = lane]
-				}
+		for (int i = 0; i < SB; ++i) {
+			T acc = (lane == i) ? T(1) : T(0);
+#pragma unroll
+			for (int k = 0; k < i; ++k) acc -= bcast(r[k], i) * wc[k];
+			wc[i] = acc * bcast(myrinv, i);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (lane < SB) {
+#pragma unroll
+			for (int k = 0; k < SB; ++k) {
+				if (k <= lane) S[tri(o + lane, o + k)] = r[k];
+				WD[(kb * SB + k) * WLD + lane] = wc[k];            // W[k][c = lane]
 			}
 		}
+	};
+	// ---- one trailing sub-block (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T  (diagonal sub-blocks: lower part only)
+	auto trail_pair = [&](int kb, int bi, int bj) {
+		const int o = kb * SB;
+		const bool diag = bi == bj;
+		v4 acc;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int rr = MM::crow(lane, q);
+			acc[q] = (!diag || r16 <= rr) ? S[tri(bi * SB + rr, bj * SB + r16)] : T(0);
+		}
+#pragma unroll
+		for (int s4 = 0; s4 < 4; ++s4)
+			acc = MM::mma(-S[tri(bi * SB + r16, o + 4 * s4 + g)], S[tri(bj * SB + r16, o + 4 * s4 + g)], acc);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int rr = MM::crow(lane, q);
+			if (!diag || r16 <= rr) S[tri(bi * SB + rr, bj * SB + r16)] = acc[q];
+		}
+	};
+
+	// One sub-block of look-ahead: after panel kb, the sub-block column kb+1 is updated first; wave 0 then factors the
+	// next diagonal sub-block (the serial part: 6.6 us of every step) while the other seven waves finish the update.
+	if (wave == 0) diag_block(0);
+	for (int kb = 0; kb < NSB; ++kb) {
+		const int o = kb * SB;
 		__syncthreads();
 		// ---- panel below: X_bi = A_bi * WD^T   (one sub-block per wave; every element is strictly below the diagonal)
 		for (int bi = kb + 1 + wave; bi < NSB; bi += 8) {
@@ -256,32 +292,21 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 			for (int q = 0; q < 4; ++q) S[tri(bi * SB + MM::crow(lane, q), o + r16)] = acc[q];
 		}
 		__syncthreads();
-		// ---- trailing sub-blocks (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T  (diagonal sub-blocks: lower part only)
-		{
-			const int nrem = NSB - 1 - kb, npair = nrem * (nrem + 1) / 2;
-			for (int pidx = wave; pidx < npair; pidx += 8) {
-				int a = 0, rem = pidx;
-				while (rem > a) { rem -= a + 1; ++a; }
-				const int bi = kb + 1 + a, bj = kb + 1 + rem;
-				const bool diag = bi == bj;
-				v4 acc;
-#pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const int rr = MM::crow(lane, q);
-					acc[q] = (!diag || r16 <= rr) ? S[tri(bi * SB + rr, bj * SB + r16)] : T(0);
-				}
-#pragma unroll
-				for (int s4 = 0; s4 < 4; ++s4)
-					acc = MM::mma(-S[tri(bi * SB + r16, o + 4 * s4 + g)], S[tri(bj * SB + r16, o + 4 * s4 + g)], acc);
-#pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const int rr = MM::crow(lane, q);
-					if (!diag || r16 <= rr) S[tri(bi * SB + rr, bj * SB + r16)] = acc[q];
+		if (kb + 1 < NSB) {
+			if (kb + 1 + wave < NSB) trail_pair(kb, kb + 1 + wave, kb + 1);      // column kb+1 (wave 0: its diagonal sub-block)
+			__syncthreads();
+			if (wave == 0) diag_block(kb + 1);
+			else {
+				const int nrem = NSB - 2 - kb, npair = nrem * (nrem + 1) / 2;
+				for (int pidx = wave - 1; pidx < npair; pidx += 7) {
+					int a = 0, rem = pidx;
+					while (rem > a) { rem -= a + 1; ++a; }
+					trail_pair(kb, kb + 2 + a, kb + 2 + rem);
 				}
 			}
 		}
-		__syncthreads();
 	}
+	__syncthreads();
 
 	// ---- write L back (and the panel copy with explicit zeros above the diagonal); inverse(L):
 	// ---- zeros above the diagonal and the diagonal sub-blocks now, off-diagonal blocks below
