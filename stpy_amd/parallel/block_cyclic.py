@@ -173,11 +173,23 @@ class DistributedGaussianProcess:
 		# sub-communicators: every rank creates every group, in the same order
 		# (RCCL: communication kernels go to high-priority streams, i.e. hardware queues of their own, so a
 		# panel broadcast is never queued behind the trailing update it is meant to overlap)
+		def make_groups(kw):
+			rows = [dist.new_group([r * self.Pc + c for c in range(self.Pc)], **kw) for r in range(self.Pr)]
+			cols = [dist.new_group([r * self.Pc + c for r in range(self.Pr)], **kw) for c in range(self.Pc)]
+			return rows, cols
 		kw = {}
 		if dist.get_backend() == "nccl":
-			kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-		self.row_groups = [dist.new_group([r * self.Pc + c for c in range(self.Pc)], **kw) for r in range(self.Pr)]
-		self.col_groups = [dist.new_group([r * self.Pc + c for r in range(self.Pr)], **kw) for c in range(self.Pc)]
+			try:
+				kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+			except Exception:        # option class not exposed by this build: plain groups
+				kw = {}
+		try:
+			self.row_groups, self.col_groups = make_groups(kw)
+		except (TypeError, ValueError, RuntimeError):
+			if not kw:
+				raise
+			# (raised identically on every rank before any communicator exists, so the retry stays collective)
+			self.row_groups, self.col_groups = make_groups({})
 		self.fitted = False
 		self.clamp_variance = False
 		self.max_size = 10000
