@@ -197,4 +197,13 @@ def main():
 
 
 if __name__ == "__main__":
-	main()
+	try:
+		main()
+	except Exception as exc:                         # noqa: BLE001
+		# a multi-GPU run that dies must still say why on the one line the driver reads (value null = not measured)
+		if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+			import traceback
+			print(json.dumps({"metric": "GP fit+mean_var wall-time (s), N=65536 d=16 fp64", "value": None, "unit": "s",
+							  "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "higher_is_better": False, "scaling": "strong",
+							  "error": "%s: %s" % (type(exc).__name__, exc), "traceback_tail": traceback.format_exc()[-1500:]}), flush=True)
+		raise
