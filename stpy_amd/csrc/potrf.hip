@@ -209,51 +209,66 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	}
 	__syncthreads();
 
-	// ---- 16x16 diagonal sub-block kb (ONE wave): factor + inverse, rows in registers (lane i < 16 holds row i)
+	// ---- 16x16 diagonal sub-block kb (ONE wave): Cholesky factor and its inverse together.
+	// Lane (q, i) = (lane >> 4, lane & 15) holds row i, columns 4q..4q+3, of the block (a[]) and of the inverse being
+	// built (w[], starts as the identity).  Pivot j: the scaled column j lives in lane group q = j/4; every lane fetches
+	// its row's multiplier and the four column-j entries of ITS columns with lane permutes, then does 4 + 4 FMAs:
+	// the right-looking update a_ik -= l_ij l_kj and the row operation W_i -= l_ij W_j that turns I into inverse(L).
+	// (The first version kept a whole row per lane on 16 lanes: 15 broadcasts + 15 FMAs per pivot in one dependent chain,
+	// then a second pass for the inverse -- 6.6 us per sub-block, three quarters of the kernel.)
 	auto diag_block = [&](int kb) {
 		const int o = kb * SB;
-		T r[SB];
+		const int q = lane >> 4, i = lane & 15;
+		T a[4], w[4];
 #pragma unroll
-		for (int k = 0; k < SB; ++k) r[k] = (lane < SB && k <= lane) ? S[tri(o + lane, o + k)] : T(0);
-		T myrinv = T(1);
+		for (int c = 0; c < 4; ++c) {
+			const int col = 4 * q + c;
+			a[c] = (col <= i) ? S[tri(o + i, o + col)] : T(0);
+			w[c] = (col == i) ? T(1) : T(0);
+		}
+		int first_bad = 0;
 #pragma unroll
 		for (int j = 0; j < SB; ++j) {
-			T d = bcast(r[j], j);
-			if (!(d > T(0)) || !(d < T(1e300))) {
-				if (lane == 0) atomicCAS(info, 0, block_row0 + o + j + 1);
-				d = T(1);
-			}
+			const int qj = j >> 2, cj = j & 3;
+			T d = bcast(a[cj], 16 * qj + j);
+			// (no branch here: one basic block over all 16 pivots lets the scheduler start the next pivot's reciprocal
+			// square root under the tail of this pivot's update; the failing pivot is reported once, after the loop)
+			const bool bad = !(d > T(0)) || !(d < T(1e300));
+			first_bad = (bad && first_bad == 0) ? j + 1 : first_bad;
+			d = bad ? T(1) : d;
 			// 1/sqrt(d) from the hardware estimate + two Newton steps, l = d * rl (no sqrt + division on the pivot chain)
 			T rl = (T)__builtin_amdgcn_rsq(d);
 			rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
 			rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
 			const T l = d * rl;
-			r[j] = (lane == j) ? l : r[j] * rl;
-			if (lane == j) myrinv = rl;
+			// scaled column j (meaningful on the lanes of group qj, rows >= j)
+			const T colv = (i == j) ? l : a[cj] * rl;
+			a[cj] = (q == qj && i >= j) ? colv : a[cj];
+			// all nine lane permutes first, then straight-line selects: with `if`s hipcc builds an exec-mask region per
+			// column and waits for each permute on its own
+			const T mi = __shfl(colv, 16 * qj + i, 64);                  // l_ij of this lane's row
+			T lk[4], wj[4];
 #pragma unroll
-			for (int k = j + 1; k < SB; ++k) {
-				const T lkj = bcast(r[j], k);
-				const T upd = r[k] - r[j] * lkj;
-				r[k] = (lane >= k) ? upd : r[k];
+			for (int c = 0; c < 4; ++c) {
+				lk[c] = __shfl(colv, 16 * qj + 4 * q + c, 64);           // l_kj of this lane's column k = 4q + c
+				wj[c] = __shfl(w[c], 16 * q + j, 64);                    // pivot row of the inverse
 			}
-			__builtin_amdgcn_sched_barrier(0);      // keep the broadcasts of later pivots from being hoisted (register pressure)
-		}
-		// inverse of the 16x16 factor: lane c holds column c of W
-		T wc[SB];
 #pragma unroll
-		for (int i = 0; i < SB; ++i) {
-			T acc = (lane == i) ? T(1) : T(0);
-#pragma unroll
-			for (int k = 0; k < i; ++k) acc -= bcast(r[k], i) * wc[k];
-			wc[i] = acc * bcast(myrinv, i);
-			__builtin_amdgcn_sched_barrier(0);
-		}
-		if (lane < SB) {
-#pragma unroll
-			for (int k = 0; k < SB; ++k) {
-				if (k <= lane) S[tri(o + lane, o + k)] = r[k];
-				WD[(kb * SB + k) * WLD + lane] = wc[k];            // W[k][c = lane]
+			for (int c = 0; c < 4; ++c) {
+				const int k = 4 * q + c;
+				const T na = a[c] - mi * lk[c];
+				a[c] = (k > j && i >= k) ? na : a[c];
+				const T ws = wj[c] * rl;
+				const T nw = w[c] - mi * ws;
+				w[c] = (i == j) ? ws : ((i > j) ? nw : w[c]);
 			}
+		}
+		if (first_bad != 0 && lane == 0) atomicCAS(info, 0, block_row0 + o + first_bad);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const int col = 4 * q + c;
+			if (col <= i) S[tri(o + i, o + col)] = a[c];
+			WD[(kb * SB + i) * WLD + col] = (col <= i) ? w[c] : T(0);       // W[row i][col]
 		}
 	};
 	// ---- one trailing sub-block (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T  (diagonal sub-blocks: lower part only)
