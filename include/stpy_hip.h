@@ -14,7 +14,9 @@
  *   - dtype: 0 = float64, 1 = float32 (all operands of one call share it);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
  *   - no allocation, no ownership transfer, no global mutable state besides a thread-local
- *     last-error string; workspaces are sized by the *_workspace_bytes queries;
+ *     last-error string; workspaces are sized by the *_workspace_bytes queries and passed with their size
+ *     (`work_bytes`): a workspace smaller than the query's answer for the same arguments is refused (-20) instead
+ *     of being overrun;
  *   - return value: 0 = ok, <0 = invalid argument (-(index of the argument), 1-based) or
  *     -1000-hipError for a failed launch; numerical failure of the factorisation is reported
  *     through the device word `info_dev` (0 = ok, j>0 = leading minor j not positive definite),
@@ -69,7 +71,7 @@ int stpy_gram(int kind, int dtype,
               int d, const int32_t* cols, const void* inv_ls,
               double kappa, double offset, double diag_add,
               int lower_only, int combine,
-              void* out, int64_t ldo, void* work, void* stream);
+              void* out, int64_t ldo, void* work, int64_t work_bytes, void* stream);
 
 /* k(x_i, x_i) for i < m -- replaces the per-point Python loop of gauss_procc.py:347 */
 int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,
@@ -87,7 +89,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,
  */
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb);
 int64_t stpy_potrf_winv_elems(int64_t n);
-int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int nb,
+int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int64_t work_bytes, int nb,
                int32_t* info_dev, void* stream);
 
 /* B <- B L^-T for B: m x n row-major (rows = right-hand sides).  With B = K* (M x N) this is
@@ -97,7 +99,7 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* wor
  * of the next panel to overlap them. */
 int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb);
 int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
-                       const void* winv, void* B, int64_t ldb, int nb, void* work, void* stream);
+                       const void* winv, void* B, int64_t ldb, int nb, void* work, int64_t work_bytes, void* stream);
 
 /*
  * Gradient of the evidence (estimator.py:156-190 drives it through
@@ -112,10 +114,10 @@ int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t l
  *   follow from H [Xs | 1] (one stpy_gemm_nt) -- see stpy_amd/continuous_processes/gauss_procc.py.
  */
 int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv,
-               void* Kinv, int64_t ldk, void* work, void* stream);
+               void* Kinv, int64_t ldk, void* work, int64_t work_bytes, void* stream);
 int stpy_lml_weight(int kind, int dtype, const void* x, int64_t n, int64_t ldx, int d,
                     const int32_t* cols, const void* inv_ls, double kappa, double weight,
-                    const void* alpha, void* H, int64_t ldh, void* work, void* stream);
+                    const void* alpha, void* H, int64_t ldh, void* work, int64_t work_bytes, void* stream);
 
 /* out = L^-1 y (trans = 0) or out = L^-T y (trans = 1); the two together are cholesky_solve,
  * estimator.py:37.  y is used as scratch (destroyed); out must not alias y. */
@@ -152,7 +154,7 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k,
 int stpy_gemm_nt_splitk_passes(int64_t m, int64_t n, int64_t k);
 int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k,
                         const void* A, int64_t lda, const void* B, int64_t ldb,
-                        void* C, int64_t ldc, int mode, int passes, void* work, void* stream);
+                        void* C, int64_t ldc, int mode, int passes, void* work, int64_t work_bytes, void* stream);
 
 /*
  * The same contraction on a window of a rank's LOCAL matrix under a 2-D block-cyclic distribution

@@ -26,22 +26,22 @@ _vp, _i64, _i32, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double
 SIGNATURES = {
 	"stpy_version": (_c.c_char_p, []),
 	"stpy_last_error_string": (_c.c_char_p, []),
-	"stpy_gram": (_i32, [_i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _i32, _i32, _vp, _i64, _vp, _vp]),
+	"stpy_gram": (_i32, [_i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
 	"stpy_gram_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32]),
 	"stpy_gram_diag": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _i32, _vp, _vp]),
 	"stpy_potrf_workspace_bytes": (_i64, [_i32, _i64, _i32]),
 	"stpy_potrf_winv_elems": (_i64, [_i64]),
-	"stpy_potrf": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+	"stpy_potrf": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp]),
 	"stpy_trsm_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32]),
-	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp]),
-	"stpy_potri": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
-	"stpy_lml_weight": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp]),
+	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+	"stpy_potri": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
+	"stpy_lml_weight": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp, _i64, _vp]),
 	"stpy_trsv": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
 	"stpy_predict": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
 	"stpy_logdet_quad": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp]),
 	"stpy_gemm_nt": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
 	"stpy_gemm_nt_splitk_passes": (_i32, [_i64, _i64, _i64]),
-	"stpy_gemm_nt_splitk": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+	"stpy_gemm_nt_splitk": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
 	"stpy_gemm_nt_bc": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 	"stpy_symmetrize_lower": (_i32, [_i32, _i64, _vp, _i64, _vp]),
 	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _dbl, _vp, _i64, _i32, _vp]),

@@ -172,7 +172,7 @@ class GaussianProcess:
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=xd.dtype, device=xd.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, n, self.nb)),), dtype=torch.uint8, device=xd.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
-		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), _lib.ptr(work), self.nb, _lib.ptr(info), _lib.stream_ptr())
+		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb, _lib.ptr(info), _lib.stream_ptr())
 		_lib.check(rc, "stpy_potrf")
 		bad = int(info.item())          # the one synchronisation of a fit
 		del work
@@ -334,7 +334,7 @@ class GaussianProcess:
 		ko._kernel_into(xd, xt, X)                                      # K* = k(x, xtest): (M, N)   :346
 		tw = torch.empty((int(lib.stpy_trsm_workspace_bytes(dt, m, n, self.nb)),), dtype=torch.uint8, device=X.device)
 		_lib.check(lib.stpy_trsm_right_lt(dt, m, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv),
-										  _lib.ptr(X), X.stride(0), self.nb, _lib.ptr(tw), st()), "stpy_trsm_right_lt")   # X = K* L^-T
+										  _lib.ptr(X), X.stride(0), self.nb, _lib.ptr(tw), tw.numel() * tw.element_size(), st()), "stpy_trsm_right_lt")   # X = K* L^-T
 		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
 		if not full:
 			kd = torch.empty((m,), dtype=xd.dtype, device=xd.device)
@@ -388,7 +388,7 @@ class GaussianProcess:
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(nn)),), dtype=C.dtype, device=C.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, nn, self.nb)),), dtype=torch.uint8, device=C.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=C.device)
-		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), C.stride(0), _lib.ptr(winv), _lib.ptr(work), self.nb, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
+		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), C.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
 		bad = int(info.item())
 		if bad != 0:
 			raise torch.linalg.LinAlgError("sample: posterior covariance + jitter is not positive definite (leading minor %d)" % bad)
@@ -491,7 +491,7 @@ class GaussianProcess:
 		alpha = self._backward_z(L, winv, z)
 		Kinv = torch.empty((n, n), dtype=L.dtype, device=L.device)
 		work = torch.empty((n, n), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_potri(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(work), st()), "stpy_potri")
+		_lib.check(lib.stpy_potri(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(work), work.numel() * work.element_size(), st()), "stpy_potri")
 		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), Kinv.stride(0), st()), "stpy_symmetrize_lower")
 		trace_G = w * Kinv.diagonal().sum() - torch.dot(alpha, alpha)                    # tr(w K^-1 - alpha alpha^T)
 
@@ -520,7 +520,7 @@ class GaussianProcess:
 					H.copy_(Kinv)
 				ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
 				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(xd), n, xd.stride(0), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
-											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(H), H.stride(0), _lib.ptr(ws), st()), "stpy_lml_weight")
+											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(H), H.stride(0), _lib.ptr(ws), ws.numel() * ws.element_size(), st()), "stpy_lml_weight")
 				# ... o M_i
 				factors = []
 				if it['op'] == "*" and i > 0:

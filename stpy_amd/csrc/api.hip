@@ -71,12 +71,17 @@ extern "C" {
 const char* stpy_version(void) { return "stpy_hip 0.1 (gfx950)"; }
 const char* stpy_last_error_string(void) { return g_err; }
 
+// a workspace that is too small is refused here: the kernels cannot check it and would write past its end
+#define WORK_CHECK(fn, have, need) do { const int64_t need_ = (need); if ((have) < need_) { \
+	set_error(fn ": workspace of %lld bytes, %lld needed (see the *_workspace_bytes query for these arguments)", (long long)(have), (long long)need_); return -20; } } while (0)
+
 int stpy_gram(int kind, int dtype, const void* a, int64_t n, int64_t lda, const void* b, int64_t q, int64_t ldb,
               int d, const int32_t* cols, const void* inv_ls, double kappa, double offset, double diag_add,
-              int lower_only, int combine, void* out, int64_t ldo, void* work, void* stream)
+              int lower_only, int combine, void* out, int64_t ldo, void* work, int64_t work_bytes, void* stream)
 {
 	if (n <= 0 || q <= 0) return 0;          // empty problem: nothing to write (empty tensors have null data pointers)
 	if (!a || !b || !out || !inv_ls) { set_error("stpy_gram: null pointer"); return -3; }
+	if (work) WORK_CHECK("stpy_gram", work_bytes, stpy_gram_workspace_bytes(dtype, n, q, d));
 	if (d <= 0 || lda < 1 || ldb < 1 || ldo < n) { set_error("stpy_gram: bad dimensions d=%d ldo=%lld n=%lld", d, (long long)ldo, (long long)n); return -9; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
@@ -108,10 +113,11 @@ int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
 
 int64_t stpy_potrf_winv_elems(int64_t n) { return ((n + IB - 1) / IB) * (int64_t)IB * IB; }
 
-int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int nb, int32_t* info_dev, void* stream)
+int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int64_t work_bytes, int nb, int32_t* info_dev, void* stream)
 {
 	if (!A || !winv || !work || !info_dev) { set_error("stpy_potrf: null pointer"); return -3; }
 	if (n <= 0 || lda < n) { set_error("stpy_potrf: bad dimensions n=%lld lda=%lld", (long long)n, (long long)lda); return -2; }
+	WORK_CHECK("stpy_potrf", work_bytes, stpy_potrf_workspace_bytes(dtype, n, nb));
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         potrf<double>(n, (double*)A, lda, (double*)winv, (double*)work, nb, info_dev, st),
@@ -126,10 +132,11 @@ int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
 	return (int64_t)TRSM_MAX_PASSES * m * nb * (int64_t)(dtype == STPY_F32 ? 4 : 8);
 }
 
-int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* work, void* stream)
+int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* work, int64_t work_bytes, void* stream)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!L || !winv || !B) { set_error("stpy_trsm_right_lt: null pointer"); return -4; }
+	if (work) WORK_CHECK("stpy_trsm_right_lt", work_bytes, stpy_trsm_workspace_bytes(dtype, m, n, nb));
 	if (m < 0 || n <= 0 || ldl < n || ldb < n) { set_error("stpy_trsm_right_lt: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
@@ -137,10 +144,11 @@ int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t l
 	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st, false, (float*)work));
 }
 
-int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* Kinv, int64_t ldk, void* work, void* stream)
+int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* Kinv, int64_t ldk, void* work, int64_t work_bytes, void* stream)
 {
 	if (!L || !winv || !Kinv || !work) { set_error("stpy_potri: null pointer"); return -3; }
 	if (n <= 0 || ldl < n || ldk < n) { set_error("stpy_potri: bad dimensions"); return -2; }
+	WORK_CHECK("stpy_potri", work_bytes, n * n * (int64_t)(dtype == STPY_F32 ? 4 : 8));
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         potri_lower<double>(n, (const double*)L, ldl, (const double*)winv, (double*)Kinv, ldk, (double*)work, st),
@@ -148,9 +156,10 @@ int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* win
 }
 
 int stpy_lml_weight(int kind, int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
-                    double kappa, double weight, const void* alpha, void* H, int64_t ldh, void* work, void* stream)
+                    double kappa, double weight, const void* alpha, void* H, int64_t ldh, void* work, int64_t work_bytes, void* stream)
 {
 	if (!x || !inv_ls || !alpha || !H || !work) { set_error("stpy_lml_weight: null pointer"); return -3; }
+	WORK_CHECK("stpy_lml_weight", work_bytes, stpy_gram_workspace_bytes(dtype, n, n, d));
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         lml_weight<double>(kind, (const double*)x, n, ldx, d, cols, (const double*)inv_ls, kappa, weight, (const double*)alpha, (double*)H, ldh, work, st),
@@ -205,11 +214,12 @@ int stpy_gemm_nt_splitk_passes(int64_t m, int64_t n, int64_t k)
 }
 
 int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int64_t lda, const void* B, int64_t ldb,
-                        void* C, int64_t ldc, int mode, int passes, void* work, void* stream)
+                        void* C, int64_t ldc, int mode, int passes, void* work, int64_t work_bytes, void* stream)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt_splitk: null pointer"); return -5; }
 	if (passes > 1 && !work) { set_error("stpy_gemm_nt_splitk: %d passes need a workspace of passes*m*n elements", passes); return -5; }
+	if (passes > 1) WORK_CHECK("stpy_gemm_nt_splitk", work_bytes, (int64_t)passes * m * n * (int64_t)(dtype == STPY_F32 ? 4 : 8));
 	if (mode != 0 && mode != 1) { set_error("stpy_gemm_nt_splitk: mode must be 0 or 1"); return -11; }
 	hipStream_t st = (hipStream_t)stream;
 	ProfScope ps(TAG_GEMM_API, 2.0 * (double)m * (double)n * (double)k, st);

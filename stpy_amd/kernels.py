@@ -324,7 +324,7 @@ class KernelFunction:
 			rc = lib.stpy_gram(t['kind'], dt, _lib.ptr(am), n, am.stride(0), _lib.ptr(bm), q, bm.stride(0),
 							   d_eff, _lib.ptr(cols), _lib.ptr(inv_ls), t['kappa'], t['offset'],
 							   diag_add if (last and not l['fold']) else 0.0, 1 if lower_only else 0, l['combine'],
-							   _lib.ptr(target), target.stride(0), _lib.ptr(work), _lib.stream_ptr())
+							   _lib.ptr(target), target.stride(0), _lib.ptr(work), work.numel() * work.element_size(), _lib.stream_ptr())
 			_lib.check(rc, "stpy_gram")
 			if l['fold']:
 				out.mul_(tmp)

@@ -99,7 +99,7 @@ class HipLocalOps:
 		winv = self.empty(int(self.lib.stpy_potrf_winv_elems(n)))
 		work = torch.empty((int(self.lib.stpy_potrf_workspace_bytes(self.code, n, self.nb)),), dtype=torch.uint8, device=self.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=self.device)
-		_lib.check(self.lib.stpy_potrf(self.code, n, _lib.ptr(A), A.stride(0), _lib.ptr(winv), _lib.ptr(work), self.nb,
+		_lib.check(self.lib.stpy_potrf(self.code, n, _lib.ptr(A), A.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb,
 									   _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
 		return winv, info
 
@@ -109,7 +109,7 @@ class HipLocalOps:
 		if m == 0:
 			return
 		_lib.check(self.lib.stpy_trsm_right_lt(self.code, m, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(B), B.stride(0),
-											   self.nb, None, _lib.stream_ptr()), "stpy_trsm_right_lt")
+											   self.nb, None, 0, _lib.stream_ptr()), "stpy_trsm_right_lt")
 
 	def gemm_nt(self, A, B, C, mode, bc=None):
 		"""C (mode 0: =, 1: -=) A B^T.  bc = (nb_dist, pr, pc, myr, myc, i0, j0) enables the staircase."""
@@ -122,7 +122,7 @@ class HipLocalOps:
 			if passes > 1:        # few output tiles, long K (partial sums of the distributed solve)
 				work = self.empty(passes * m * n)
 				_lib.check(self.lib.stpy_gemm_nt_splitk(self.code, m, n, k, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0),
-														mode, passes, _lib.ptr(work), _lib.stream_ptr()), "stpy_gemm_nt_splitk")
+														mode, passes, _lib.ptr(work), work.numel() * work.element_size(), _lib.stream_ptr()), "stpy_gemm_nt_splitk")
 				return
 			rc = self.lib.stpy_gemm_nt(self.code, m, n, k, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0),
 									   mode, 0, _lib.stream_ptr())

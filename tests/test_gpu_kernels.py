@@ -65,12 +65,12 @@ def test_gemm_nt_splitk(L, m, n, k, mode, passes):
 	Ad, Bd, Cd = dev(A), dev(B), dev(C)
 	work = torch.full((passes * m * n,), float("nan"), dtype=torch.float64, device="cuda:0")
 	lib = L.load()
-	L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, passes, L.ptr(work), L.stream_ptr()), "splitk")
+	L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, passes, L.ptr(work), work.numel() * work.element_size(), L.stream_ptr()), "splitk")
 	ref = A @ B.T if mode == 0 else C - A @ B.T
 	assert rel_err(Cd.cpu().numpy(), ref) < 1e-13
 	# the same call twice gives the same bits (fixed summation order)
 	Cd2 = dev(C)
-	L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd2), n, mode, passes, L.ptr(work), L.stream_ptr()), "splitk")
+	L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd2), n, mode, passes, L.ptr(work), work.numel() * work.element_size(), L.stream_ptr()), "splitk")
 	assert torch.equal(Cd, Cd2)
 
 
@@ -80,7 +80,7 @@ def test_gemm_nt_splitk_plan(L):
 	assert lib.stpy_gemm_nt_splitk_passes(4096, 512, 512) == 1          # short K
 	assert lib.stpy_gemm_nt_splitk_passes(8192, 8192, 65536) == 1       # plenty of tiles
 	assert lib.stpy_gemm_nt_splitk_passes(1, 512, 65536) == 1           # row kernel instead
-	assert lib.stpy_gemm_nt_splitk(L.F64, 256, 256, 4096, 1, 4096, 1, 4096, 1, 256, 0, 4, None, None) != 0
+	assert lib.stpy_gemm_nt_splitk(L.F64, 256, 256, 4096, 1, 4096, 1, 4096, 1, 256, 0, 4, None, 0, None) != 0
 	assert b"workspace" in lib.stpy_last_error_string()
 
 
@@ -111,6 +111,25 @@ def test_gemm_nt_k128_small_grid(L, m, n, mode):
 		out = bd.cpu().numpy()
 		assert rel_err(out[:, 128:256], big[:, 128:256] @ B.T) < 1e-13
 		assert np.array_equal(out[:, :128], big[:, :128]) and np.array_equal(out[:, 256:], big[:, 256:])
+
+
+def test_undersized_workspace_is_refused(L):
+	"""a workspace smaller than the query's answer comes back as error -20, not as a write past its end"""
+	lib = L.load()
+	n = 1024
+	Kd = dev(np.eye(n) * 2.0)
+	winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device="cuda:0")
+	info = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+	small = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, 256)), dtype=torch.uint8, device="cuda:0")
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(small), small.numel(), 512, L.ptr(info), L.stream_ptr()) == -20
+	assert b"workspace" in lib.stpy_last_error_string()
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(small), small.numel(), 256, L.ptr(info), L.stream_ptr()) == 0
+	x = dev(np.random.RandomState(0).normal(size=(300, 5)))
+	il = dev(np.ones(5))
+	out = torch.empty((300, 300), dtype=torch.float64, device="cuda:0")
+	tiny = torch.empty(64, dtype=torch.uint8, device="cuda:0")
+	assert lib.stpy_gram(0, L.F64, L.ptr(x), 300, 5, L.ptr(x), 300, 5, 5, None, L.ptr(il), 1.0, 0.0, 0.0, 0, 0, L.ptr(out), 300, L.ptr(tiny), 64, L.stream_ptr()) == -20
+	torch.cuda.synchronize()
 
 
 def test_gemm_nt_asymmetric_layout(L):
@@ -200,7 +219,7 @@ def workspace(L, n, q, d, dtype=torch.float64):
 def test_gram_kinds(L, name, kind, n, q, d, use_ws):
 	"""use_ws=False: direct tile kernel; True: MFMA contraction + fused epilogue (not for Matern 1/2)"""
 	ws = workspace(L, n, q, d) if use_ws else None
-	WORK = L.ptr(ws)
+	WORK, WORK_BYTES = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
 	rng = np.random.RandomState(n + q + d + kind)
 	a, b = rng.uniform(-1, 1, size=(n, d)), rng.uniform(-1, 1, size=(q, d))
 	inv_ls = rng.uniform(0.3, 1.5, size=d) if kind != 4 else np.ones(d)
@@ -208,7 +227,7 @@ def test_gram_kinds(L, name, kind, n, q, d, use_ws):
 	out = torch.empty((q, n), dtype=torch.float64, device="cuda:0")
 	lib = L.load()
 	L.check(lib.stpy_gram(kind, L.F64, L.ptr(ad), n, d, L.ptr(bd), q, d, d, None, L.ptr(ild), 1.3, 0.25, 0.0, 0, 0,
-						  L.ptr(out), n, WORK, L.stream_ptr()), "gram")
+						  L.ptr(out), n, WORK, WORK_BYTES, L.stream_ptr()), "gram")
 	ref = oracle_gram(kind, a, b, inv_ls, 1.3, 0.25, None)
 	assert out.shape == (q, n)
 	assert rel_err(out.cpu().numpy(), ref) < 1e-13
@@ -219,7 +238,7 @@ def test_gram_cols_combine_diag_lower(L, use_ws):
 	rng = np.random.RandomState(3)
 	n, d = 333, 6
 	ws = workspace(L, n, n, d) if use_ws else None
-	WORK = L.ptr(ws)
+	WORK, WORK_BYTES = L.ptr(ws), (ws.numel() * ws.element_size() if ws is not None else 0)
 	x = rng.uniform(-1, 1, size=(n, d))
 	xd = dev(x)
 	cols = [0, 2, 5]
@@ -229,19 +248,19 @@ def test_gram_cols_combine_diag_lower(L, use_ws):
 	out = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
 	ild, il2d = dev(inv_ls), dev(np.full(d, 0.7))
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(ild), 1.1, 0.0, 0.0, 0, L.OUT_SET,
-						  L.ptr(out), n, WORK, L.stream_ptr()), "gram")
+						  L.ptr(out), n, WORK, WORK_BYTES, L.stream_ptr()), "gram")
 	k1 = oracle_gram(0, x, x, inv_ls, 1.1, 0.0, cols)
 	assert rel_err(out.cpu().numpy(), k1) < 1e-13
 	# product with a Matern 5/2 on all columns, then diag_add on the last item
 	il2 = np.full(d, 0.7)
 	L.check(lib.stpy_gram(3, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, d, None, L.ptr(il2d), 0.9, 0.0, 0.04, 0, L.OUT_MUL,
-						  L.ptr(out), n, WORK, L.stream_ptr()), "gram")
+						  L.ptr(out), n, WORK, WORK_BYTES, L.stream_ptr()), "gram")
 	k2 = k1 * oracle_gram(3, x, x, il2, 0.9, 0.0, None) + 0.04 * np.eye(n)
 	assert rel_err(out.cpu().numpy(), k2) < 1e-13
 	# lower_only: lower triangle identical, sum with ADD
 	out2 = torch.full((n, n), 7.0, dtype=torch.float64, device="cuda:0")
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(xd), n, d, L.ptr(xd), n, d, 3, L.ptr(colsd), L.ptr(ild), 1.1, 0.0, 0.5, 1, L.OUT_SET,
-						  L.ptr(out2), n, WORK, L.stream_ptr()), "gram")
+						  L.ptr(out2), n, WORK, WORK_BYTES, L.stream_ptr()), "gram")
 	o2 = out2.cpu().numpy()
 	il = np.tril_indices(n)
 	assert rel_err(o2[il], (k1 + 0.5 * np.eye(n))[il]) < 1e-13
@@ -278,7 +297,7 @@ def run_potrf(L, K, nb=0, dtype=torch.float64):
 	winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=dtype, device="cuda:0")
 	work = torch.empty((int(lib.stpy_potrf_workspace_bytes(code, n, nb)),), dtype=torch.uint8, device="cuda:0")
 	info = torch.full((1,), -5, dtype=torch.int32, device="cuda:0")
-	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(work), nb, L.ptr(info), L.stream_ptr()), "potrf")
+	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), nb, L.ptr(info), L.stream_ptr()), "potrf")
 	return Kd, winv, int(info.item())
 
 
@@ -321,7 +340,7 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	lib = L.load()
 	B = rng.normal(size=(m, n))
 	Bd = dev(B)
-	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, nb, None, L.stream_ptr()), "trsm")
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, nb, None, 0, L.stream_ptr()), "trsm")
 	Xref = sla.solve_triangular(Lref, B.T, lower=True).T
 	assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 	# the same solve with the K-pass workspace
@@ -333,7 +352,7 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 		assert (wb == 0) == (n <= (nb if nb > 0 else 512))
 		Bw = dev(B)
 		wk = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda:0")
-		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), L.stream_ptr()), "trsm")
+		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), wk.numel() * wk.element_size(), L.stream_ptr()), "trsm")
 		assert rel_err(Bw.cpu().numpy(), Xref) < 1e-11
 	finally:
 		lib.stpy_tune(5, 0)
@@ -369,7 +388,7 @@ def test_potri(L, n, nb):
 	lib = L.load()
 	Kinv = torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda:0")
 	work = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
-	L.check(lib.stpy_potri(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Kinv), n, L.ptr(work), L.stream_ptr()), "potri")
+	L.check(lib.stpy_potri(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Kinv), n, L.ptr(work), work.numel() * work.element_size(), L.stream_ptr()), "potri")
 	out = Kinv.cpu().numpy()
 	ref = np.linalg.inv(K)
 	il = np.tril_indices(n)
@@ -451,7 +470,7 @@ def test_rff_f32(L):
 def test_error_reporting(L):
 	lib = L.load()
 	WORK = None
-	rc = lib.stpy_gram(99, L.F64, None, 1, 1, None, 1, 1, 1, None, None, 1.0, 0.0, 0.0, 0, 0, None, 1, WORK, L.stream_ptr())
+	rc = lib.stpy_gram(99, L.F64, None, 1, 1, None, 1, 1, 1, None, None, 1.0, 0.0, 0.0, 0, 0, None, 1, WORK, 0, L.stream_ptr())
 	assert rc < 0 and b"null" in lib.stpy_last_error_string()
 	x = dev(np.zeros((2, 2)))
 	rc = lib.stpy_gemm_nt(7, 2, 2, 2, L.ptr(x), 2, L.ptr(x), 2, L.ptr(x), 2, 0, 0, L.stream_ptr())

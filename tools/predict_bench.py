@@ -33,7 +33,7 @@ def main():
 				gp.kernel_object._kernel_into(gp._xd, xt, X)
 				torch.cuda.synchronize(); t0 = time.perf_counter()
 				L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), L.ptr(X), X.stride(0), nb,
-											   L.ptr(wk) if use_work else None, L.stream_ptr()), "trsm")
+											   L.ptr(wk) if use_work else None, wk.numel() if use_work else 0, L.stream_ptr()), "trsm")
 				torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 			t = min(ts)
 			print("trsm n=%d m=%d nb=%d work=%d depth=%d wg=%d: %.1f ms  %.1f TF" % (n, m, nb, use_work, depth, wgt, t * 1e3, float(m) * n * n / t / 1e12), flush=True)

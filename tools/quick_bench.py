@@ -45,14 +45,14 @@ def bench_potrf(n, nb):
 	work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), dtype=torch.uint8, device=dev)
 	info = torch.zeros(1, dtype=torch.int32, device=dev)
 	ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, 16)), dtype=torch.uint8, device=dev)
-	gram0 = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, None, L.stream_ptr()), "gram")
-	gram = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), L.stream_ptr()), "gram")
+	gram0 = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, None, 0, L.stream_ptr()), "gram")
+	gram = lambda: L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel() * ws.element_size(), L.stream_ptr()), "gram")
 	t0, _ = timeit(gram0)
 	t, _ = timeit(gram)
 	print("gram lower n=%d: tile kernel %.3f ms %.2f TB/s | MFMA+epilogue %.3f ms  %.2f TB/s" % (n, t0 * 1e3, n * n * 8 * 0.5 / t0 / 1e12, t * 1e3, n * n * 8 * 0.5 / t / 1e12), flush=True)
 	def f():
 		gram()
-		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), nb, L.ptr(info), L.stream_ptr()), "potrf")
+		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), nb, L.ptr(info), L.stream_ptr()), "potrf")
 	t2, _ = timeit(f, reps=2)
 	tp = t2 - t
 	print("potrf n=%d nb=%d: %.3f ms  %.1f TF/s  info=%d" % (n, nb, tp * 1e3, n ** 3 / 3.0 / tp / 1e12, int(info.item())), flush=True)
@@ -172,7 +172,7 @@ def leftlook():
 			if tiles * passes > 1024 or tiles >= 512:
 				continue
 			W = torch.empty(passes * m * n, dtype=torch.float64, device=dev)
-			f2 = lambda: L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(A), lda, L.ptr(B), lda, L.ptr(C), n, 1, passes, L.ptr(W), L.stream_ptr()), "gemm")
+			f2 = lambda: L.check(lib.stpy_gemm_nt_splitk(L.F64, m, n, k, L.ptr(A), lda, L.ptr(B), lda, L.ptr(C), n, 1, passes, L.ptr(W), W.numel() * W.element_size(), L.stream_ptr()), "gemm")
 			t2 = timeit(f2, reps=3, warm=1)[0]
 			msg += " | %d passes %.3f ms %.1f TF" % (passes, t2 * 1e3, 2.0 * m * n * k / t2 / 1e12)
 			del W
