@@ -99,6 +99,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, i
 {
 	if (m <= 0) return 0;
 	if (!x || !out || !inv_ls) { set_error("stpy_gram_diag: null pointer"); return -3; }
+	if (d < 0 || ldx < 1) { set_error("stpy_gram_diag: bad dimensions"); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         gram_diag<double>(kind, (const double*)x, m, ldx, d, cols, (const double*)inv_ls, kappa, offset, combine, (double*)out, st),
@@ -181,6 +182,7 @@ int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, co
 {
 	if (m <= 0) return 0;
 	if (!X || !z || (sigma && !kdiag && clamp != 2)) { set_error("stpy_predict: null pointer"); return -4; }
+	if (n < 0 || ldx < n) { set_error("stpy_predict: ldx=%lld < n=%lld", (long long)ldx, (long long)n); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         predict<double>(m, n, (const double*)X, ldx, (const double*)z, (const double*)kdiag, (double*)mu, (double*)sigma, clamp, st),
@@ -190,6 +192,7 @@ int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, co
 int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const void* z, void* out2, void* stream)
 {
 	if (!L || !out2) { set_error("stpy_logdet_quad: null pointer"); return -3; }
+	if (n <= 0 || ldl < n) { set_error("stpy_logdet_quad: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         logdet_quad<double>(n, (const double*)L, ldl, (const double*)z, (double*)out2, st),
@@ -201,6 +204,7 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int6
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt: null pointer"); return -5; }
+	if (k < 0 || lda < k || ldb < k || ldc < n) { set_error("stpy_gemm_nt: leading dimensions lda=%lld ldb=%lld (k=%lld) ldc=%lld (n=%lld)", (long long)lda, (long long)ldb, (long long)k, (long long)ldc, (long long)n); return -6; }
 	hipStream_t st = (hipStream_t)stream;
 	ProfScope ps(TAG_GEMM_API, (lower_only && m == n) ? (double)m * (double)n * (double)k : 2.0 * (double)m * (double)n * (double)k, st);
 	DISPATCH(dtype,
@@ -218,6 +222,7 @@ int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k, const void* 
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt_splitk: null pointer"); return -5; }
+	if (k < 0 || lda < k || ldb < k || ldc < n) { set_error("stpy_gemm_nt_splitk: leading dimensions"); return -6; }
 	if (passes > 1 && !work) { set_error("stpy_gemm_nt_splitk: %d passes need a workspace of passes*m*n elements", passes); return -5; }
 	if (passes > 1) WORK_CHECK("stpy_gemm_nt_splitk", work_bytes, (int64_t)passes * m * n * (int64_t)(dtype == STPY_F32 ? 4 : 8));
 	if (mode != 0 && mode != 1) { set_error("stpy_gemm_nt_splitk: mode must be 0 or 1"); return -11; }
@@ -233,6 +238,7 @@ int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, i
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt_bc: null pointer"); return -5; }
+	if (k < 0 || lda < k || ldb < k || ldc < n) { set_error("stpy_gemm_nt_bc: leading dimensions"); return -6; }
 	if (pr <= 0 || pc <= 0 || myr < 0 || myr >= pr || myc < 0 || myc >= pc || i0 < 0 || j0 < 0) { set_error("stpy_gemm_nt_bc: bad process-grid arguments"); return -13; }
 	hipStream_t st = (hipStream_t)stream;
 	BlockCyclic bc{nb_dist, pr, pc, myr, myc, i0, j0};
@@ -245,6 +251,7 @@ int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, i
 int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stream)
 {
 	if (!A) { set_error("stpy_symmetrize_lower: null pointer"); return -3; }
+	if (n <= 0 || lda < n) { set_error("stpy_symmetrize_lower: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype, symmetrize_lower<double>(n, (double*)A, lda, st), symmetrize_lower<float>(n, (float*)A, lda, st));
 }
