@@ -55,7 +55,7 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 	seen = 0
 	for b in blocks:
 		name = b.split()[0]
-		if "gemm_nt_kernel" not in name and "potf2_trtri_mfma_kernel" not in name and "gemm_nt_dtv_kernel" not in name:
+		if "gemm_nt_kernel" not in name and "potf2_trtri_mfma_kernel" not in name and "gemm_nt_dtv_kernel" not in name and "gemm_nt_k128_kernel" not in name:
 			continue
 		seen += 1
 		scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
@@ -70,6 +70,8 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 			else:
 				assert scratch < 400, (name, scratch, vspill)
 			assert vgprs <= 256
+		elif "gemm_nt_k128_kernel" in name:
+			assert vspill == 0 and scratch == 0 and vgprs <= 128, (name, vgprs, scratch)
 		elif "gemm_nt_dtv_kernel" in name:
 			# direct-to-VGPR GEMM: a spill there also means hipcc reloads before the loop and waits for them inside it,
 			# which drains the hand-counted load queue
