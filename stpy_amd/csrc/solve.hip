@@ -188,8 +188,8 @@ int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int6
 // `out`; updates go to the not-yet-solved part of y only, so there is no hazard on y_c.
 // ------------------------------------------------------------------------------------------
 constexpr int TV_THREADS = 256;
-constexpr int TV_ROWS = 256;     // rows of L per workgroup in the forward sweep
-constexpr int TV_COLS = 256;     // columns of L per workgroup in the backward sweep
+constexpr int TV_ROWS = 128;     // rows of L per workgroup in the forward sweep (8 passes of 16 rows, all loads in flight at once)
+constexpr int TV_COLS = 128;     // columns of L per workgroup in the backward sweep (two threads per column, 64 rows each)
 
 template <typename T>
 __global__ __launch_bounds__(TV_THREADS)
@@ -200,14 +200,26 @@ void trsv_fwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W
 	const int tid = threadIdx.x;
 	if (tid < IB) yc[tid] = tid < cb ? y[c + tid] : T(0);
 	__syncthreads();
-	// t = W y_c : two threads per row
+	// t = W y_c : 16 lanes per row, each with 8 consecutive columns (one coalesced 1 KiB read per row), 16 rows in flight,
+	// all eight passes' loads issued before the first is consumed (the first version gave a thread half a row to walk
+	// through alone: 64 dependent, uncoalesced loads in front of every step of the sweep)
 	{
-		const int r = tid >> 1, h = tid & 1;
-		T s = T(0);
-		const T* wr = W + r * IB + h * 64;
-		for (int k = 0; k < 64; ++k) s += wr[k] * yc[h * 64 + k];
-		s += __shfl_xor(s, 1);
-		if (h == 0) tc[r] = s;
+		const int l16 = tid & 15, rsub = tid >> 4;
+		T yv[8], wv[8][8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) yv[e] = yc[l16 * 8 + e];
+#pragma unroll
+		for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+			for (int e = 0; e < 8; ++e) wv[ps][e] = W[(ps * 16 + rsub) * IB + l16 * 8 + e];
+#pragma unroll
+		for (int ps = 0; ps < 8; ++ps) {
+			T s = T(0);
+#pragma unroll
+			for (int e = 0; e < 8; ++e) s += wv[ps][e] * yv[e];
+			s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+			if (l16 == 0) tc[ps * 16 + rsub] = s;
+		}
 	}
 	__syncthreads();
 	if (blockIdx.x == 0) {
@@ -220,16 +232,27 @@ void trsv_fwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W
 	T tv[8];
 #pragma unroll
 	for (int e = 0; e < 8; ++e) tv[e] = tc[l16 * 8 + e];
-	for (int r0 = 0; r0 < TV_ROWS; r0 += 16) {
-		const int r = row_base + r0 + rsub;
-		T s = T(0);
-		if (r < n) {
-			const T* lr = L + (int64_t)r * ldl + c + l16 * 8;
+	// one memory round trip for the whole workgroup: the eight passes' row segments and the y entries they update are all
+	// requested before the first product (the sweep is a chain of n/128 launches; each used to take four round trips)
+	constexpr int NPS = TV_ROWS / 16;
+	T lv[NPS][8], yold[NPS];
 #pragma unroll
-			for (int e = 0; e < 8; ++e) if (l16 * 8 + e < cb) s += lr[e] * tv[e];
-		}
+	for (int ps = 0; ps < NPS; ++ps) {
+		const int r = row_base + ps * 16 + rsub;
+		const int rc = r < n ? r : n - 1;
+		const T* lr = L + (int64_t)rc * ldl + c + l16 * 8;
+#pragma unroll
+		for (int e = 0; e < 8; ++e) lv[ps][e] = (l16 * 8 + e < cb) ? lr[e] : T(0);
+		yold[ps] = y[rc];
+	}
+#pragma unroll
+	for (int ps = 0; ps < NPS; ++ps) {
+		const int r = row_base + ps * 16 + rsub;
+		T s = T(0);
+#pragma unroll
+		for (int e = 0; e < 8; ++e) s += lv[ps][e] * tv[e];
 		s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-		if (r < n && l16 == 0) y[r] -= s;
+		if (r < n && l16 == 0) y[r] = yold[ps] - s;
 	}
 }
 
@@ -246,6 +269,7 @@ void trsv_bwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W
 	{
 		const int k = tid & 127, h = tid >> 7;
 		T s = T(0);
+#pragma unroll 16
 		for (int i = h * 64; i < h * 64 + 64; ++i) s += W[i * IB + k] * yc[i];
 		if (h == 1) tc[k] = s;
 		__syncthreads();
@@ -256,13 +280,26 @@ void trsv_bwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W
 		if (tid < cb) out[c + tid] = tc[tid];
 		return;
 	}
-	// y[j] -= sum_i L[c+i][j] t[i]  for this workgroup's columns j < c
-	const int j = (blockIdx.x - 1) * TV_COLS + tid;
-	if (j >= c) return;
+	// y[j] -= sum_i L[c+i][j] t[i]  for this workgroup's columns j < c: two threads per column (64 rows each, lanes along j
+	// so every row segment is one coalesced read), all 64 loads of a thread in flight together -- one memory round trip
+	const int jl = tid & (TV_COLS - 1), hf = tid >> 7;
+	const int j = (blockIdx.x - 1) * TV_COLS + jl;
+	const bool live = j < c;
+	const int jc = live ? j : 0;
+	T lv[64];
+#pragma unroll
+	for (int i = 0; i < 64; ++i) {
+		const int row = hf * 64 + i;
+		lv[i] = (live && row < cb) ? L[(int64_t)(c + (row < cb ? row : 0)) * ldl + jc] : T(0);
+	}
+	const T yold = y[jc];
 	T s = T(0);
-	const T* lp = L + (int64_t)c * ldl + j;
-	for (int i = 0; i < cb; ++i) s += lp[(int64_t)i * ldl] * tc[i];
-	y[j] -= s;
+#pragma unroll
+	for (int i = 0; i < 64; ++i) s += lv[i] * tc[hf * 64 + i];
+	__shared__ T red[TV_COLS];
+	if (hf == 1) red[jl] = s;
+	__syncthreads();
+	if (hf == 0 && live) y[j] = yold - (s + red[jl]);
 }
 
 template <typename T>

@@ -1,0 +1,23 @@
+import sys, time, torch
+sys.path.insert(0, ".")
+from stpy_amd import GaussianProcess, _lib as L
+lib = L.load()
+dev = torch.device("cuda:0")
+for n in (16384, 65536):
+	d = 8
+	g = torch.Generator().manual_seed(1)
+	x = (torch.rand(n, d, generator=g, dtype=torch.float64) * 2 - 1).to(dev)
+	y = torch.sin(x.sum(1, keepdim=True))
+	gp = GaussianProcess(gamma=d ** 0.5, s=0.1, kernel_name="squared_exponential", d=d)
+	gp.fit_gp(x, y)
+	yv = y.reshape(-1).clone(); z = torch.empty(n, dtype=torch.float64, device=dev); a = torch.empty(n, dtype=torch.float64, device=dev)
+	for tr in (0, 1):
+		ts = []
+		for _ in range(4):
+			src = yv.clone()
+			torch.cuda.synchronize(); t0 = time.perf_counter()
+			L.check(lib.stpy_trsv(L.F64, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), L.ptr(src), L.ptr(z), tr, L.stream_ptr()), "trsv")
+			torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+		print("n=%d trsv trans=%d: %.2f ms (%.1f us per 128-block step)" % (n, tr, min(ts) * 1e3, min(ts) * 1e6 / (n / 128)), flush=True)
+	del gp, x, y
+	torch.cuda.empty_cache()
