@@ -454,17 +454,29 @@ def test_rff_transposed(L, dtype, tol):
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
 
 
-def test_rff_f32(L):
-	rng = np.random.RandomState(2)
-	n, d, m = 300, 64, 512
+@pytest.mark.parametrize("n,d,m", [(300, 64, 512), (256, 64, 512), (384, 32, 256), (128, 96, 128)])
+def test_rff_f32(L, n, d, m):
+	"""fp32 embed with the trig fused into the GEMM's store: ragged (register staging) and tile-aligned (LDS-DMA, K tiles
+	of 32 floats) shapes, plain / biased / transposed"""
+	rng = np.random.RandomState(2 + n + d + m)
 	x, W = rng.uniform(0, 1, size=(n, d)).astype(np.float32), (rng.normal(size=(m, d)) / 8.0).astype(np.float32)
+	b = (2 * np.pi * rng.uniform(size=m)).astype(np.float32)
 	lib = L.load()
+	xd, Wd, bd = dev(x, torch.float32), dev(W, torch.float32), dev(b, torch.float32)
+	x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
+	scale = float(np.sqrt(2.0 / m))
 	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
-	xd, Wd = dev(x, torch.float32), dev(W, torch.float32)
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None,
-							   float(np.sqrt(2.0 / m)), L.ptr(out), m, 0, L.stream_ptr()), "rff")
-	ref = O.rff_embed(x.astype(np.float64), W.astype(np.float64), m)
-	assert np.abs(out.cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max() * 10
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	ref = O.rff_embed(x64, W64, m)
+	assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	refb = O.rff_embed(x64, W64, m, b=b64)            # (m, n) in the reference's biased orientation
+	assert np.abs(out.cpu().numpy() - refb.T).max() < 2e-5 * np.abs(refb).max()
+	outT = torch.empty((m, n), dtype=torch.float32, device="cuda:0")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
+	assert np.abs(outT.cpu().numpy() - ref.T).max() < 2e-5 * np.abs(ref).max()
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
+	assert np.abs(outT.cpu().numpy() - refb).max() < 2e-5 * np.abs(refb).max()
 
 
 def test_error_reporting(L):
