@@ -180,6 +180,19 @@ def test_gemm_nt_strided_submatrix(L):
 	assert rel_err(Cd.cpu().numpy(), C - A @ B.T) < 1e-13
 
 
+@pytest.mark.parametrize("m,n,k,mode", [(384, 256, 256, 0), (512, 512, 1024, 1), (256, 128, 64, 1), (1024, 384, 96, 0)])
+def test_gemm_nt_f32_aligned(L, m, n, k, mode):
+	"""fp32 on the tile-aligned paths (direct-to-VGPR kernel from k = 128, LDS-DMA kernel below; K tiles of 32 floats)"""
+	rng = np.random.RandomState(m + n + k)
+	A, B, C = [rng.normal(size=sh).astype(np.float32) for sh in ((m, k), (n, k), (m, n))]
+	Ad, Bd, Cd = dev(A, torch.float32), dev(B, torch.float32), dev(C, torch.float32)
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt(L.F32, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr()), "gemm")
+	P = A.astype(np.float64) @ B.astype(np.float64).T
+	ref = P if mode == 0 else C.astype(np.float64) - P
+	assert np.abs(Cd.cpu().numpy() - ref).max() < 2e-6 * np.sqrt(k) * max(1.0, np.abs(ref).max())
+
+
 def test_gemm_nt_f32(L):
 	rng = np.random.RandomState(9)
 	m, n, k = 384, 256, 200
