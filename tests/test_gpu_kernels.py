@@ -132,6 +132,33 @@ def test_undersized_workspace_is_refused(L):
 	torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("m,n,k,nbd,pr,pc,myr,myc,i0,j0", [
+	(1024, 768, 256, 256, 2, 2, 1, 0, 1, 0),        # aligned: direct-to-VGPR kernel with the staircase predicate
+	(1024, 1024, 128, 128, 1, 4, 0, 2, 3, 0),
+	(900, 640, 256, 128, 2, 4, 0, 3, 0, 1),         # ragged rows: guarded kernel
+	(512, 512, 512, 512, 1, 1, 0, 0, 2, 2),         # one process: plain lower staircase at distribution-block granularity
+])
+def test_gemm_nt_bc_staircase(L, m, n, k, nbd, pr, pc, myr, myc, i0, j0):
+	"""stpy_gemm_nt_bc: C -= A B^T on the 128x128 tiles whose distribution block (I, J) has I >= J, others untouched"""
+	rng = np.random.RandomState(m + n + k + myr + myc)
+	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
+	Ad, Bd, Cd = dev(A), dev(B), dev(C)
+	lib = L.load()
+	L.check(lib.stpy_gemm_nt_bc(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, 1, nbd, pr, pc, myr, myc, i0, j0, L.stream_ptr()), "gemm_bc")
+	out = Cd.cpu().numpy()
+	full = C - A @ B.T
+	nbt = nbd // 128
+	for ti in range((m + 127) // 128):
+		for tj in range((n + 127) // 128):
+			I = (ti // nbt + i0) * pr + myr
+			J = (tj // nbt + j0) * pc + myc
+			blk = (slice(ti * 128, min(m, ti * 128 + 128)), slice(tj * 128, min(n, tj * 128 + 128)))
+			if I >= J:
+				assert rel_err(out[blk], full[blk]) < 1e-13, (ti, tj)
+			else:
+				assert np.array_equal(out[blk], C[blk]), (ti, tj)
+
+
 def test_gemm_nt_asymmetric_layout(L):
 	"""A = I with an asymmetric B: catches a transposed C/D fragment map (cdna guide section 3)."""
 	n = 128
