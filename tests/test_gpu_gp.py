@@ -750,6 +750,33 @@ def test_config2_properties(S):
 	assert rel_err(N(mus), mo) < TOL and rel_err(N(stds), so) < TOL
 
 
+def test_headline_size_properties(S):
+	"""The benchmarked configuration itself (N = 65 536, d = 16, M = 4096, fp64): size-independent identities.
+	mean(x_i) = y_i - s^2 alpha_i on training points (i.e. (K + s^2 I) alpha = y, through the prediction path),
+	0 <= sigma <= sqrt(kappa), sigma at training points below the prior, and linearity of the mean in y."""
+	n, d, m = 65536, 16, 4096
+	x, y, xt = synth(n, d, m)
+	gamma, s = float(np.sqrt(d)), 0.1
+	xd, yd, xtd = x.cuda(), y.cuda(), xt.cuda()
+	GP = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(xd, yd)
+	mu, std = GP.mean_std(xtd)
+	assert not bool(torch.isnan(mu).any()) and not bool(torch.isnan(std).any())
+	assert bool(torch.all(std >= 0)) and bool(torch.all(std <= 1.0 + 1e-12))
+	idx = torch.arange(0, n, n // 2048, device="cuda")[:2048]
+	mu_tr, std_tr = GP.mean_std(xd[idx])
+	alpha = GP.A.reshape(-1, 1).cuda()
+	expect = yd[idx] - s * s * alpha[idx]
+	assert float(torch.norm(mu_tr - expect) / torch.norm(expect)) < 1e-8
+	assert float(std_tr.max()) < 1.0 and float(std_tr.mean()) < float(std.mean()) + 1e-12
+	lm = lml(GP)
+	assert np.isfinite(lm)
+	GP2 = S.GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP2.fit_gp(xd, -3.0 * yd)
+	mu2, std2 = GP2.mean_std(xtd)
+	assert rel_err(N(mu2), -3.0 * N(mu)) < 1e-9 and rel_err(N(std2), N(std)) < 1e-10
+
+
 def test_fp32_mode(S):
 	"""fp32 is a build-only precision mode (the reference is fp64-only); oracle = fp64 on the same
 	(up-cast) inputs, tolerance 1e-3 with s >= 0.3 (hard parts)."""
