@@ -93,7 +93,14 @@ def main():
 		local_rank = local_rank % max(torch.cuda.device_count(), 1)
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
-	if world > 1:
+	# STPY_BENCH_FORCE_DIST=1: take the block-cyclic code path (process group, sub-communicators, panel
+	# pipeline) even with one rank -- a functional check of the RCCL set-up on a one-GPU box
+	force_dist = world == 1 and os.environ.get("STPY_BENCH_FORCE_DIST", "0") == "1"
+	dist_path = world > 1 or force_dist
+	if force_dist:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+		os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+	if dist_path:
 		import torch.distributed as dist
 		if backend == "nccl":
 			dist.init_process_group(backend="nccl", device_id=dev)
@@ -107,7 +114,7 @@ def main():
 	gamma, s = math.sqrt(d), 0.1
 	x, y, xt = synth(n, d, m, dev)
 
-	if world > 1:
+	if dist_path:
 		from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
 		gp = DistributedGaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
 	else:
@@ -119,7 +126,7 @@ def main():
 		return gp.mean_std(xt)
 
 	def barrier():
-		if world > 1:
+		if dist_path:
 			torch.distributed.barrier()
 		torch.cuda.synchronize()
 
@@ -147,13 +154,13 @@ def main():
 	tags = {"syrk": 0, "panel_gemm": 1, "trsm_gemm": 2, "potf2": 3, "gemm_api": 4}
 	pr = {k: prof(v) for k, v in tags.items()}
 	# the block-cyclic path issues its trailing updates through stpy_gemm_nt_bc (tag 4)
-	gemm_tags = ["syrk", "panel_gemm", "trsm_gemm"] + (["gemm_api"] if world > 1 else [])
+	gemm_tags = ["syrk", "panel_gemm", "trsm_gemm"] + (["gemm_api"] if dist_path else [])
 	g_ms = sum(pr[t][0] for t in gemm_tags)
 	g_fl = sum(pr[t][1] for t in gemm_tags)
 	g_cnt = sum(pr[t][2] for t in gemm_tags)
 	# launches on the look-ahead stream overlap the trailing update: time them as the union of intervals
 	ub, uf, uc = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-	_lib.check(lib.stpy_profile_read_union(0b0111 if world == 1 else 0b10111, ctypes.byref(ub), ctypes.byref(uf), ctypes.byref(uc)), "stpy_profile_read_union")
+	_lib.check(lib.stpy_profile_read_union(0b10111 if dist_path else 0b0111, ctypes.byref(ub), ctypes.byref(uf), ctypes.byref(uc)), "stpy_profile_read_union")
 	achieved = uf.value / (ub.value * 1e-3) / 1e12 if ub.value > 0 else 0.0
 
 	# HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
@@ -163,7 +170,7 @@ def main():
 	try:
 		import glob
 		cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-		if cands and n == 65536 and d == 16 and m == 4096 and world == 1:
+		if cands and n == 65536 and d == 16 and m == 4096 and not dist_path:
 			with open(cands[-1]) as fh:
 				traffic = round(json.load(fh)["per_launch_hbm_bytes"])
 	except Exception:
@@ -177,11 +184,11 @@ def main():
 			"ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": False,
 			"scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: %s backend, ranks share one GPU)" % backend,
 			"config": {"workload": "GaussianProcess.fit_gp + mean_std, SE kernel gamma=sqrt(d), s=0.1, N=%d train, M=%d test, d=%d, fp64" % (n, m, d),
-					   "n": n, "m": m, "d": d, "nb": args.nb or ("potrf 1024, trsm 512 (library defaults)" if world == 1 else "distribution block %d" % gp.NB),
-					   "parallelism": "single GPU" if world == 1 else "2-D block-cyclic over %d GPUs" % world},
+					   "n": n, "m": m, "d": d, "nb": args.nb or ("distribution block %d" % gp.NB if dist_path else "potrf 1024, trsm 512 (library defaults)"),
+					   "parallelism": "2-D block-cyclic over %d GPU%s" % (world, "s" if world > 1 else " (forced: functional check of the distributed code path)") if dist_path else "single GPU"},
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),
-			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_dtv_kernel<SUB> (+ gemm_nt_kernel<double,...> for the ragged / fused-epilogue launches)" if world == 1 else "stpy::gemm_nt_dtv_kernel / gemm_nt_kernel<double>", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
+			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_dtv_kernel / gemm_nt_kernel<double>" if dist_path else "stpy::gemm_nt_dtv_kernel<SUB> (+ gemm_nt_kernel<double,...> for the ragged / fused-epilogue launches)", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
 						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
 						 "traffic_note": "HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes of this command (profiles/), 2*FETCH_SIZE + WRITE_SIZE",
 						 "launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4), "busy_ms_per_step": round(ub.value / args.steps, 2),
@@ -192,7 +199,7 @@ def main():
 		if world == 1 and not args.no_cpu_baseline:
 			out["cpu_baseline"] = cpu_baseline(d)
 		print(json.dumps(out), flush=True)
-	if world > 1:
+	if dist_path:
 		torch.distributed.destroy_process_group()
 
 

@@ -242,7 +242,17 @@ int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, i
 	if (pr <= 0 || pc <= 0 || myr < 0 || myr >= pr || myc < 0 || myc >= pc || i0 < 0 || j0 < 0) { set_error("stpy_gemm_nt_bc: bad process-grid arguments"); return -13; }
 	hipStream_t st = (hipStream_t)stream;
 	BlockCyclic bc{nb_dist, pr, pc, myr, myc, i0, j0};
-	ProfScope ps(TAG_GEMM_API, 2.0 * (double)m * (double)n * (double)k, st);
+	// algorithmic flops: only the distribution blocks on or below the global diagonal are computed
+	double elems = (double)m * (double)n;
+	if (g_prof_on && nb_dist >= 128 && nb_dist % 128 == 0) {
+		elems = 0;
+		for (int64_t bi = 0; bi * nb_dist < m; ++bi) {
+			const int64_t I = (bi + i0) * pr + myr, rows = std::min<int64_t>(nb_dist, m - bi * nb_dist);
+			for (int64_t bj = 0; bj * nb_dist < n; ++bj)
+				if (I >= (bj + j0) * pc + myc) elems += (double)rows * (double)std::min<int64_t>(nb_dist, n - bj * nb_dist);
+		}
+	}
+	ProfScope ps(TAG_GEMM_API, 2.0 * elems * (double)k, st);
 	DISPATCH(dtype,
 	         gemm_nt<double>(m, n, k, (const double*)A, lda, (const double*)B, ldb, (double*)C, ldc, (double*)nullptr, 0, mode, 0, st, &bc),
 	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, 0, st, &bc));

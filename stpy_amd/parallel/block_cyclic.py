@@ -265,9 +265,10 @@ class DistributedGaussianProcess:
 			xc = xd[gc.clamp(max=n - 1)].contiguous()
 			ops.gram(self.kernel_object, xc, xr, Aloc)
 			# padding (global index >= n): identity block; noise s^2 on the global diagonal
-			if int(gr[-1]) >= n:
+			# (the last local index is host arithmetic: ((nloc-1)*P + my)*NB + NB-1 -- no device read-back)
+			if ((nr - 1) * Pr + myr + 1) * NB > n:
 				Aloc[gr >= n, :] = 0
-			if int(gc[-1]) >= n:
+			if ((nc - 1) * Pc + myc + 1) * NB > n:
 				Aloc[:, gc >= n] = 0
 			s2 = float(self.s) ** 2
 			for i in range(nr):
@@ -285,6 +286,8 @@ class DistributedGaussianProcess:
 		# caching allocator never recycles them while the other stream still reads them)
 		prow_buf = [ops.empty(max(nr * NB, 1), NB) for _ in range(2)]
 		pcol_buf = [ops.empty(max(nc * NB, 1), NB) for _ in range(2)]
+
+		lcm = Pr * Pc // math.gcd(Pr, Pc)
 
 		def panel_step(K, slot):
 			"""Steps 1-4 of the header for block column K on the CURRENT stream: diagonal factor + its
@@ -315,19 +318,25 @@ class DistributedGaussianProcess:
 			if rows_below > 0:
 				self._bcast(prow, self._rank_of(myr, kc), self.row_groups[myr], Pc)
 			# column operand: L_JK for this rank's local block columns J > K
+			# The wanted J (J % Pc == myc, J % Pr == rp, J > K) form an arithmetic progression with stride
+			# lcm(Pr, Pc), so source and destination are strided slices: no index tensors, no host sync.
 			for rp in range(Pr):
-				Js = [J for J in range(K + 1, nblk) if J % Pc == myc and J % Pr == rp]
-				if not Js:
+				J0 = next((J for J in range(K + 1, min(nblk, K + 1 + lcm)) if J % Pc == myc and J % Pr == rp), None)
+				if J0 is None:
 					continue
+				cnt = (nblk - 1 - J0) // lcm + 1
 				i0p = self._first_local_above(K, rp, Pr)
+				a, sa = J0 // Pr - i0p, lcm // Pr
+				b, sb = J0 // Pc - j0, lcm // Pc
+				dst = pcol.reshape(-1, NB, NB)[b:b + (cnt - 1) * sb + 1:sb]
 				if myr == rp:
-					sel = torch.tensor([J // Pr - i0p for J in Js], device=xd.device)
-					buf = prow.reshape(-1, NB, NB).index_select(0, sel).reshape(-1, NB)
+					src = prow.reshape(-1, NB, NB)[a:a + (cnt - 1) * sa + 1:sa]
+					buf = src if sa == 1 else src.contiguous()
 				else:
-					buf = ops.empty(len(Js) * NB, NB)
+					buf = dst if sb == 1 else ops.empty(cnt * NB, NB).reshape(cnt, NB, NB)
 				self._bcast(buf, self._rank_of(rp, myc), self.col_groups[myc], Pr)
-				dst = torch.tensor([J // Pc - j0 for J in Js], device=xd.device)
-				pcol.reshape(-1, NB, NB).index_copy_(0, dst, buf.reshape(-1, NB, NB))
+				if buf is not dst:
+					dst.copy_(buf)
 			return i0, j0, prow, pcol
 
 		# One block column of look-ahead: after panel K is in place, the local update of block column
@@ -337,9 +346,14 @@ class DistributedGaussianProcess:
 		# same statements simply run in order.
 		on_gpu = xd.is_cuda
 		main = torch.cuda.current_stream() if on_gpu else None
-		side = torch.cuda.Stream(priority=-1) if on_gpu else None
-		ev_col = torch.cuda.Event() if on_gpu else None
-		ev_panel = torch.cuda.Event() if on_gpu else None
+		# (ONE side stream per object: the caching allocator keeps a pool per stream, so a fresh stream per
+		# fit would turn every panel buffer of a re-fit into a hipMalloc / hipFree with its device sync)
+		if on_gpu and getattr(self, "_side", None) is None:
+			self._side = torch.cuda.Stream(priority=-1)
+			self._ev_col, self._ev_panel = torch.cuda.Event(), torch.cuda.Event()
+		side = self._side if on_gpu else None
+		ev_col = self._ev_col if on_gpu else None
+		ev_panel = self._ev_panel if on_gpu else None
 
 		cur = panel_step(0, 0)
 		for K in range(nblk):

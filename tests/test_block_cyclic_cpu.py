@@ -61,6 +61,8 @@ def _worker(rank, world, port, grid, n, d, m, nb_dist, kernel_name, nu, q):
 	(4, (2, 2), 900, 128, "squared_exponential", 1.5),
 	(4, (1, 4), 640, 128, "matern", 1.5),
 	(4, (4, 1), 300, 128, "squared_exponential", 1.5),
+	(6, (2, 3), 1500, 128, "squared_exponential", 1.5),      # lcm 6: strided column exchange on both sides
+	(8, (2, 4), 2100, 128, "squared_exponential", 1.5),      # the 8-GPU default grid
 ])
 def test_block_cyclic_matches_oracle(world, grid, n, nb_dist, kernel_name, nu):
 	d, m = 3, 37

@@ -17,7 +17,7 @@ def main():
 	backend = os.environ.get("STPY_BACKEND", "gloo")
 	dist.init_process_group(backend=backend)
 	from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
-	dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+	dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count() if backend == "nccl" else 0)
 	torch.cuda.set_device(dev)
 	d = 16
 	g = torch.Generator().manual_seed(1234)
@@ -26,7 +26,7 @@ def main():
 	xt = (torch.rand(m, d, generator=g, dtype=torch.float64) * 2 - 1).to(dev)
 	for nb in nbs:
 		gp = DistributedGaussianProcess(gamma=d ** 0.5, s=0.1, kernel_name="squared_exponential", d=d, nb_dist=nb)
-		for it in range(2):
+		for it in range(int(os.environ.get('STPY_ITERS', '2'))):
 			torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
 			gp.fit_gp(x, y)
 			torch.cuda.synchronize(); dist.barrier(); t1 = time.perf_counter()
