@@ -53,6 +53,11 @@ class _LogMarginalFn(torch.autograd.Function):
 		return (None, None, None, None) + tuple(scale.to(g.device) * g for g in grads)
 
 
+def _tile_pad(n):
+	"""Order at which an n x n SPD matrix is held on the device: the next multiple of the 128 x 128 GEMM tile."""
+	return -(-int(n) // 128) * 128
+
+
 class GaussianProcess:
 
 	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", diameter=1.0,
@@ -160,15 +165,26 @@ class GaussianProcess:
 	def _factor(self, xd, kwargs=None, Sigma=None):
 		"""K_theta = k(x,x) + s^2 I (or + Sigma^T Sigma) -> in-place Cholesky.  Returns (L, winv)."""
 		lib = _lib.load()
-		n = xd.shape[0]
+		n0 = xd.shape[0]
+		n = _tile_pad(n0)
 		dt = _lib.dtype_code(xd.dtype)
-		K = torch.empty((n, n), dtype=xd.dtype, device=xd.device)
+		# The matrix is held at the next multiple of the 128-tile, bordered by an identity block:
+		# chol([[K, 0], [0, I]]) = [[L, 0], [0, I]], so every product of the factorisation and of the
+		# solves below runs on the tile-aligned kernels whatever N is (a ragged N = 32 700 cost 30 %).
+		# Padded entries of y, z, alpha and the padded columns of K* are zero and drop out of every sum.
+		Kp = torch.empty((n, n), dtype=xd.dtype, device=xd.device)
+		K = Kp[:n0, :n0]
+		if n > n0:
+			Kp[n0:, :].zero_()
+			Kp[:n0, n0:].zero_()              # (upper part of the last diagonal tile: the diagonal-block kernel loads whole tiles)
+			Kp[n0:, n0:].diagonal().fill_(1.0)
 		if Sigma is None:
 			self.kernel_object._kernel_into(xd, xd, K, kwargs, diag_add=float(self.s) ** 2, lower_only=True)
 		else:
 			# general noise matrix (gauss_procc.py:163): K += Sigma^T Sigma through the NT product
 			self.kernel_object._kernel_into(xd, xd, K, kwargs)
 			self._add_noise_gram(K, Sigma)
+		K = Kp
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=xd.dtype, device=xd.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, n, self.nb)),), dtype=torch.uint8, device=xd.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
@@ -181,9 +197,10 @@ class GaussianProcess:
 		return K, winv
 
 	def _forward_y(self, L, winv, yd):
-		"""z = L^-1 y."""
+		"""z = L^-1 y (length = the padded order of L; the padding of y is zero)."""
 		lib = _lib.load()
-		scratch = yd.reshape(-1).clone()
+		scratch = torch.zeros((L.shape[0],), dtype=L.dtype, device=L.device)
+		scratch[:yd.numel()] = yd.reshape(-1)
 		z = torch.empty_like(scratch)
 		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(z), 0,
 								 _lib.stream_ptr()), "stpy_trsv")
@@ -202,7 +219,7 @@ class GaussianProcess:
 	def _alpha(self):
 		"""K^-1 y = L^-T z on the device (filled by fit_gp)."""
 		if self._alpha_cache is None and self.fitted:
-			self._alpha_cache = self._backward_z(self._L, self._winv, self._z)
+			self._alpha_cache = self._backward_z(self._L, self._winv, self._z)[:self.n]
 		return self._alpha_cache
 
 	@property
@@ -227,7 +244,7 @@ class GaussianProcess:
 		self._z = self._forward_y(self._L, self._winv, self._yd)
 		# A = K^-1 y is part of the fitted state the reference leaves behind (gauss_procc.py:376): computed
 		# eagerly even though mean_std itself only needs z
-		self._alpha_cache = self._backward_z(self._L, self._winv, self._z)
+		self._alpha_cache = self._backward_z(self._L, self._winv, self._z)[:self.n]
 		self.fitted = True
 		return None
 
@@ -330,10 +347,16 @@ class GaussianProcess:
 		m, n = xt.shape[0], self.n
 		dt = _lib.dtype_code(xd.dtype)
 		st = _lib.stream_ptr
-		X = torch.empty((m, n), dtype=xd.dtype, device=xd.device)
-		ko._kernel_into(xd, xt, X)                                      # K* = k(x, xtest): (M, N)   :346
-		tw = torch.empty((int(lib.stpy_trsm_workspace_bytes(dt, m, n, self.nb)),), dtype=torch.uint8, device=X.device)
-		_lib.check(lib.stpy_trsm_right_lt(dt, m, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv),
+		n0, n = n, self._L.shape[0]                                     # n: order of the (tile-padded) factor
+		mp = _tile_pad(m)                                               # rows of K* padded to the tile as well (zero rows)
+		X = torch.empty((mp, n), dtype=xd.dtype, device=xd.device)
+		ko._kernel_into(xd, xt, X[:m, :n0])                             # K* = k(x, xtest): (M, N)   :346
+		if n > n0:
+			X[:, n0:].zero_()
+		if mp > m:
+			X[m:, :].zero_()
+		tw = torch.empty((int(lib.stpy_trsm_workspace_bytes(dt, mp, n, self.nb)),), dtype=torch.uint8, device=X.device)
+		_lib.check(lib.stpy_trsm_right_lt(dt, mp, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv),
 										  _lib.ptr(X), X.stride(0), self.nb, _lib.ptr(tw), tw.numel() * tw.element_size(), st()), "stpy_trsm_right_lt")   # X = K* L^-T
 		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
 		if not full:
@@ -482,16 +505,19 @@ class GaussianProcess:
 		lib = _lib.load()
 		from ..kernels import _dev_const
 		L, winv, z = state
-		n = L.shape[0]
+		npad = L.shape[0]                               # tile-padded order of the factor (see _factor)
 		dt = _lib.dtype_code(L.dtype)
 		items = kernel._resolve(dict(X) if X else {})
 		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
 		st = _lib.stream_ptr
 		xd = self._xd
-		alpha = self._backward_z(L, winv, z)
-		Kinv = torch.empty((n, n), dtype=L.dtype, device=L.device)
-		work = torch.empty((n, n), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_potri(dt, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(work), work.numel() * work.element_size(), st()), "stpy_potri")
+		n = xd.shape[0]
+		alpha = self._backward_z(L, winv, z)[:n]
+		Kinv_p = torch.empty((npad, npad), dtype=L.dtype, device=L.device)
+		work_p = torch.empty((npad, npad), dtype=L.dtype, device=L.device)
+		_lib.check(lib.stpy_potri(dt, npad, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv_p), Kinv_p.stride(0), _lib.ptr(work_p), work_p.numel() * work_p.element_size(), st()), "stpy_potri")
+		# inverse of the bordered matrix = [[K^-1, 0], [0, I]]: everything below works on the leading n x n views
+		Kinv, work = Kinv_p[:n, :n], work_p[:n, :n]
 		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), Kinv.stride(0), st()), "stpy_symmetrize_lower")
 		trace_G = w * Kinv.diagonal().sum() - torch.dot(alpha, alpha)                    # tr(w K^-1 - alpha alpha^T)
 
@@ -542,7 +568,7 @@ class GaussianProcess:
 				S = (xs * xs * h.unsqueeze(1)).sum(dim=0) - (xs * P[:, :dg]).sum(dim=0)
 				g_ls = S * inv_ls                                                             # d/d(lengthscale) per coordinate of the term
 				acc[(str(i), term['pname'])].index_add_(0, torch.tensor(term['pidx'], device=L.device), g_ls)
-		del work
+		del work, work_p
 		for key, name, t in wanted:
 			if (key, name) not in acc or int(key) >= len(items) or not any(tm['pname'] == name for tm in items[int(key)]['terms']):
 				raise NotImplementedError("evidence gradient: kernel item %s has no '%s' lengthscale on the device path" % (key, name))

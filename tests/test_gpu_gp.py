@@ -717,6 +717,40 @@ def test_mid_size_vs_oracle(S, kernel_name, nu):
 	assert abs(lml(GP) - lm_o) / abs(lm_o) < TOL
 
 
+@pytest.mark.parametrize("n,m", [(3001, 777), (2177, 129), (129, 1)])
+def test_ragged_sizes_vs_oracle(S, n, m):
+	"""N and M off the 128 tile: the estimator holds the factor (and K*) at the next tile multiple, bordered by
+	an identity block / zero rows; mean, std, full covariance, alpha, norm, evidence and its gradient must not see it."""
+	d = 5
+	x, y, xt = synth(n, d, m, seed=77)
+	gamma, s = 1.7, 0.2
+	GP = S.GaussianProcess(gamma=gamma, s=s, kappa=1.3, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(x.cuda(), y.cuda())
+	assert GP._L.shape[0] % 128 == 0 and GP._L.shape[0] >= n and GP.A.shape == (n, 1)
+	mu, std = GP.mean_std(xt.cuda())
+	assert mu.shape == (m, 1) and std.shape == (m, 1)
+	spec = [("squared_exponential", dict(gamma=gamma, kappa=1.3), "-")]
+	L, alpha = O.fit(x.numpy(), y.numpy(), spec, s)
+	mu_o, std_o = O.mean_std(x.numpy(), L, alpha, xt.numpy(), spec)
+	assert rel_err(N(mu), mu_o) < TOL and rel_err(N(std), std_o) < TOL
+	assert rel_err(N(GP.A), alpha) < 1e-7
+	mu_f, cov = GP.mean_std(xt.cuda(), full=True)
+	_, cov_o = O.mean_cov(x.numpy(), L, alpha, xt.numpy(), spec)
+	assert cov.shape == (m, m) and rel_err(N(cov), cov_o) < TOL and rel_err(N(mu_f), mu_o) < TOL
+	assert rel_err(N(GP.norm()), O.norm(x.numpy(), alpha, spec)) < 1e-7
+	lm_o = O.log_marginal(x.numpy(), y.numpy(), spec, s)[0, 0]
+	assert abs(lml(GP) - lm_o) / abs(lm_o) < TOL
+	# gradient of the evidence w.r.t. the lengthscale against torch autograd of the same formula on the CPU
+	g = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+	f = GP.log_marginal(GP.kernel_object, {'0': {'gamma': g}}, 1.0)
+	f.backward()
+	gr = torch.tensor(gamma, dtype=torch.float64, requires_grad=True)
+	fr = _torch_lml(x, y, s, 1.0, "se", gr, 1.3)
+	fr.backward()
+	assert abs(float(f) - float(fr)) / abs(float(fr)) < 1e-9
+	assert abs(float(g.grad) - float(gr.grad)) / abs(float(gr.grad)) < 1e-7
+
+
 def test_config2_properties(S):
 	"""BASELINE config 2: N=16 384, d=8 SE, fp64.  Size-independent checks: (K+s^2 I) alpha = y,
 	interpolation-consistency of mean(x) = K alpha, 0 <= sigma <= sqrt(kappa), a 2 048-point oracle
