@@ -193,6 +193,8 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
 void stpy_profile_enable(int enable);
 /* tuning knob for A/B benchmarks: key 0 = first-round workgroup stagger of the GEMM (default 1) */
 void stpy_tune(int key, int value);
+/* current value of a switch (-1: unknown key), so a caller can restore what it changed */
+int stpy_tune_get(int key);
 int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* launches);
 /* union of the launch intervals of all tags in tagmask (bit t = tag t): overlapping launches counted once */
 int stpy_profile_read_union(int tagmask, double* busy_ms, double* total_flops, int64_t* launches);

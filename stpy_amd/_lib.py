@@ -48,6 +48,7 @@ SIGNATURES = {
 	"stpy_profile_enable": (None, [_i32]),
 	"stpy_profile_read_union": (_i32, [_i32, _c.POINTER(_dbl), _c.POINTER(_dbl), _c.POINTER(_i64)]),
 	"stpy_tune": (None, [_i32, _i32]),
+	"stpy_tune_get": (_i32, [_i32]),
 	"stpy_profile_read": (_i32, [_i32, _c.POINTER(_dbl), _c.POINTER(_dbl), _c.POINTER(_i64)]),
 }
 

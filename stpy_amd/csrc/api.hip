@@ -293,6 +293,22 @@ void stpy_tune(int key, int value)
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
+int stpy_tune_get(int key)
+{
+	switch (key) {
+	case 0: return g_gemm_stagger;
+	case 1: return g_gemm_exp;
+	case 2: return g_potf2_scalar;
+	case 3: return g_trsm_pass_depth;
+	case 4: return g_trsm_wg_target;
+	case 5: return g_trsm_right_looking;
+	case 6: return g_gemm_dtv;
+	case 7: return g_potrf_diag_first_below;
+	case 8: return g_gemm_k128;
+	default: return -1;
+	}
+}
+
 void stpy_profile_enable(int enable)
 {
 	g_prof_on = enable != 0;

@@ -78,6 +78,17 @@ class HipLocalOps:
 	def empty(self, *shape):
 		return torch.empty(shape, dtype=self.dtype, device=self.device)
 
+	def beside_update(self, on):
+		"""Brackets the launches of a panel step that is enqueued while the trailing update occupies the chip.
+		The one-volley K = 128 kernel holds 128 KiB of LDS, i.e. it needs a CU with no update workgroup on
+		it, and without preemption it then waits for the update's grid to drain (13.8 ms for a 14-workgroup
+		product in the trace of N = 65 536); the 32 KiB kernels fit beside one update workgroup."""
+		if on:
+			self._k128_saved = int(self.lib.stpy_tune_get(8))
+			self.lib.stpy_tune(8, 0)
+		else:
+			self.lib.stpy_tune(8, self._k128_saved)
+
 	def zeros(self, *shape):
 		return torch.zeros(shape, dtype=self.dtype, device=self.device)
 
@@ -259,6 +270,9 @@ class DistributedGaussianProcess:
 		gr = global_index(nr, myr, Pr)
 		gc = global_index(nc, myc, Pc)
 		self._gc = gc
+		self._Aloc = self._zloc = None          # release the previous factor before allocating the next one
+		self._winv = {}
+		self.fitted = False
 		Aloc = ops.empty(max(nr * NB, 1), max(nc * NB, 1))
 		if nr > 0 and nc > 0:
 			xr = xd[gr.clamp(max=n - 1)].contiguous()
@@ -375,7 +389,11 @@ class DistributedGaussianProcess:
 			if on_gpu:
 				with torch.cuda.stream(side):
 					side.wait_event(ev_col)
-					cur = panel_step(K + 1, (K + 1) % 2)
+					ops.beside_update(True)
+					try:
+						cur = panel_step(K + 1, (K + 1) % 2)
+					finally:
+						ops.beside_update(False)
 					ev_panel.record(side)
 				main.wait_event(ev_panel)
 			else:

@@ -17,6 +17,10 @@ def main():
 	backend = os.environ.get("STPY_BACKEND", "gloo")
 	dist.init_process_group(backend=backend)
 	from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
+	from stpy_amd import _lib
+	for kv in filter(None, os.environ.get("STPY_TUNE", "").split(",")):       # e.g. STPY_TUNE="8=0" (no K=128 volley kernel)
+		k, v = kv.split("=")
+		_lib.load().stpy_tune(int(k), int(v))
 	dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count() if backend == "nccl" else 0)
 	torch.cuda.set_device(dev)
 	d = 16
