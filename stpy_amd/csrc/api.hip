@@ -290,6 +290,7 @@ void stpy_tune(int key, int value)
 	if (key == 6) g_gemm_dtv = value;
 	if (key == 7) g_potrf_diag_first_below = value;
 	if (key == 8) g_gemm_k128 = value;
+	if (key == 9) g_rff_tile = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
@@ -305,6 +306,7 @@ int stpy_tune_get(int key)
 	case 6: return g_gemm_dtv;
 	case 7: return g_potrf_diag_first_below;
 	case 8: return g_gemm_k128;
+	case 9: return g_rff_tile;
 	default: return -1;
 	}
 }

@@ -17,6 +17,7 @@ inline int potrf_auto_nb(int64_t n) { return n <= 16384 ? 256 : (n <= 32768 ? 51
 extern int g_gemm_stagger;
 extern int g_gemm_exp;
 extern int g_gemm_dtv, g_gemm_dtv_min_k, g_gemm_k128;
+extern int g_rff_tile;
 extern int g_potf2_scalar;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

@@ -523,7 +523,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			for (int tn = 0; tn < 4; ++tn) {
 				if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
 				if (SUB && DMA) acc[tm][tn][i] = -acc[tm][tn][i];
-				crow[tn * 16] = acc[tm][tn][i];
+				// streaming outputs (embedding, Gram matrix: far larger than the caches) bypass the L2 allocation
+				// so that the operand tiles the next workgroups re-read stay resident
+				if constexpr (EPI == 2 || EPI == 3) __builtin_nontemporal_store(acc[tm][tn][i], &crow[tn * 16]);
+				else crow[tn * 16] = acc[tm][tn][i];
 			}
 		}
 	if (p.C2) {         // second copy (panel workspace of potrf): one uniform branch around all its stores

@@ -16,6 +16,8 @@
 
 namespace stpy {
 
+int g_rff_tile = 1;             // dedicated fp32 tile kernel for d = 32 / 64 (stpy_tune key 9; 0 = always the GEMM epilogue)
+
 __global__ __launch_bounds__(256)
 void rff_trig_f64_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias, double scale)
 {
@@ -44,6 +46,105 @@ void rff_trig_f64_t_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int
 	out[(int64_t)j * ldo + i] = scale * ((bias || j < half) ? cos(q) : sin(q));
 }
 
+// ---- fp32, d = 32 or 64, tile-aligned shapes: 128 x 64 output tile per workgroup, the whole contraction
+// staged ONCE (no K loop, one barrier), 52 KiB of LDS so that THREE workgroups share a CU: the phases of a
+// tile (operand fetch - MFMA - trig + 64 KiB of stores) are strictly serial inside a workgroup, and with
+// two resident workgroups the MFMA pipe sat idle 45 % of the time.  Waves 2 x 2, wave tile 64 x 32.
+// Both sin and cos go through v_cos_f32 (argument in revolutions): t = q/2pi + b/2pi (- 1/4 for the sine
+// columns), reduced by v_fract.  The k index is permuted consistently for both operands (lane group kq
+// reads the float4 at k = 16 g + 4 kq), which a dot product does not notice and which makes every LDS
+// read a 16-byte one.  Column tiles vary fastest, so the eight XCDs each keep one eighth of W in their L2.
+// `exp` (stpy_tune key 1, 0 in production) switches phases off for tools/rff_ablate.py: 1 no stores, 2 no MFMA,
+// 4 no operand loads.
+template <int D>
+__global__ __launch_bounds__(256, 3)
+void rff_tile_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                         float* __restrict__ out, int64_t ldo, int col_tiles, int half,
+                         const float* __restrict__ bias, float scale, int exp)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	constexpr int LD = D + 4;             // rows shift by 4 banks: a quarter wave's ds_read_b128 touches every bank once
+	constexpr int F4 = D / 4;
+	constexpr int CLD = 36;               // row stride of the output staging (see the store phase)
+	__shared__ __attribute__((aligned(16))) float smem[(192 * LD > 4 * 64 * CLD) ? 192 * LD : 4 * 64 * CLD];
+	float* const As = smem;
+	float* const Bs = smem + 128 * LD;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+	const int r16 = lane & 15, kq = lane >> 4;
+	const int ct = (int)(blockIdx.x % (unsigned)col_tiles);
+	const int64_t row0 = (int64_t)(blockIdx.x / (unsigned)col_tiles) * 128;
+	const int col0 = ct * 64;
+
+	const float* xa = x + row0 * ldx;
+	const float* wb = W + (int64_t)col0 * ldw;
+	if (!(exp & 4)) {
+#pragma unroll
+	for (int it = 0; it < (128 * F4) / 256; ++it) {
+		const int idx = tid + it * 256, r = idx / F4, c = idx % F4;
+		*(v4f*)&As[r * LD + 4 * c] = *(const v4f*)(xa + (int64_t)r * ldx + 4 * c);
+	}
+#pragma unroll
+	for (int it = 0; it < (64 * F4) / 256; ++it) {
+		const int idx = tid + it * 256, r = idx / F4, c = idx % F4;
+		*(v4f*)&Bs[r * LD + 4 * c] = *(const v4f*)(wb + (int64_t)r * ldw + 4 * c);
+	}
+	}
+	__syncthreads();
+
+	v4f acc[4][2];
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = v4f{0.f, 0.f, 0.f, 0.f};
+	if (!(exp & 2))
+#pragma unroll
+	for (int g = 0; g < D / 16; ++g) {
+		v4f a[4], b[2];
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm) a[tm] = *(const v4f*)&As[(wm * 64 + tm * 16 + r16) * LD + 16 * g + 4 * kq];
+#pragma unroll
+		for (int tn = 0; tn < 2; ++tn) b[tn] = *(const v4f*)&Bs[(wn * 32 + tn * 16 + r16) * LD + 16 * g + 4 * kq];
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 2; ++tn)
+					acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][c], b[tn][c], acc[tm][tn], 0, 0, 0);
+	}
+
+	constexpr float INV_2PI = 0.15915494309189535f;
+	float off[2];
+#pragma unroll
+	for (int tn = 0; tn < 2; ++tn) {
+		const int col = col0 + wn * 32 + tn * 16 + r16;
+		off[tn] = bias ? bias[col] * INV_2PI : (col < half ? 0.f : -0.25f);
+	}
+	// The MFMA result layout gives 64-byte row segments per store instruction (16 lanes x 4 B).  Each wave
+	// turns its 64 x 32 sub-tile through LDS (the operand images are dead after the barrier) and stores
+	// 16 bytes per lane: 8 lanes = one 128-byte line, 8 full lines per instruction, 8 instructions.
+	// (CLD = 36: rows 4 apart are 16 banks apart, so the four kq groups of a write do not collide)
+	__syncthreads();
+	float* const cw = smem + wave * (64 * CLD);
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn) {
+				const float t = __builtin_amdgcn_fractf(__builtin_fmaf(acc[tm][tn][i], INV_2PI, off[tn]));
+				cw[(tm * 16 + 4 * kq + i) * CLD + tn * 16 + r16] = scale * __builtin_amdgcn_cosf(t);
+			}
+	if ((exp & 1) && scale != 12345.f) return;
+	const int rr = lane >> 3, c4 = (lane & 7) * 4;
+	float* const obase = out + (row0 + wm * 64 + rr) * ldo + (col0 + wn * 32 + c4);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const v4f v = *(const v4f*)&cw[(rr + 8 * j) * CLD + c4];
+		__builtin_nontemporal_store(v, (v4f*)(obase + (int64_t)(8 * j) * ldo));
+	}
+}
+
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
               const T* bias, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
@@ -54,6 +155,14 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 {
 	if (n <= 0 || m <= 0) return 0;
 	if (m % 2 != 0) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
+	if (g_rff_tile && !transposed && (d == 32 || d == 64) && n % 128 == 0 && m % 64 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
+	    (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0 && (n / 128) * (m / 64) < (int64_t)INT32_MAX && m < (int64_t)INT32_MAX) {
+		const int col_tiles = (int)(m / 64);
+		const dim3 grid((unsigned)((n / 128) * col_tiles));
+		if (d == 64) hipLaunchKernelGGL(rff_tile_f32_kernel<64>, grid, dim3(256), 0, st, x, ldx, W, ldw, out, ldo, col_tiles, (int)(m / 2), bias, (float)scale, g_gemm_exp);
+		else         hipLaunchKernelGGL(rff_tile_f32_kernel<32>, grid, dim3(256), 0, st, x, ldx, W, ldw, out, ldo, col_tiles, (int)(m / 2), bias, (float)scale, g_gemm_exp);
+		return check_launch("rff_tile_f32");
+	}
 	RffEpilogue<float> epi{(int)(m / 2), (float)scale, bias, transposed ? 1 : 0};
 	if (transposed) return gemm_nt<float>(m, n, d, W, ldw, x, ldx, out, ldo, (float*)nullptr, 0, 2, 0, st, nullptr, &epi);
 	return gemm_nt<float>(n, m, d, x, ldx, W, ldw, out, ldo, (float*)nullptr, 0, 2, 0, st, nullptr, &epi);

@@ -84,6 +84,19 @@ def test_mfma_kernels_stay_in_registers(src, tmp_path):
 	assert seen >= 2
 
 
+def test_rff_tile_kernel_fits_three_per_cu(tmp_path):
+	"""rff_tile_f32_kernel relies on three co-resident workgroups per CU: <= 53 KiB of LDS, <= 168 VGPRs, no scratch."""
+	out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", os.path.join(CSRC, "rff.hip"),
+						  "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True).stderr
+	blocks = [b for b in re.split(r"remark: Function Name: ", out)[1:] if "rff_tile_f32_kernel" in b.split()[0]]
+	assert len(blocks) == 2
+	for b in blocks:
+		assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0
+		assert int(re.search(r"\bVGPRs: (\d+)", b).group(1)) <= 168
+		assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) <= 53 * 1024
+		assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) >= 3
+
+
 def test_dtv_kernel_fragments_are_not_copied(tmp_path):
 	"""gemm_nt_dtv_kernel loads A fragments with inline asm and guards them with hand-counted waits.  The compiler believes
 	the asm's output is valid at once; if it ever copied a fragment register between the load and its wait, the copy

@@ -494,10 +494,11 @@ def test_rff_transposed(L, dtype, tol):
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
 
 
-@pytest.mark.parametrize("n,d,m", [(300, 64, 512), (256, 64, 512), (384, 32, 256), (128, 96, 128)])
+@pytest.mark.parametrize("n,d,m", [(300, 64, 512), (256, 64, 512), (384, 32, 256), (128, 96, 128), (128, 64, 192), (640, 32, 64)])
 def test_rff_f32(L, n, d, m):
-	"""fp32 embed with the trig fused into the GEMM's store: ragged (register staging) and tile-aligned (LDS-DMA, K tiles
-	of 32 floats) shapes, plain / biased / transposed"""
+	"""fp32 embed: the dedicated 128 x 64 tile kernel (d = 32 / 64, n % 128 == 0, m % 64 == 0; m = 192 puts the cos / sin
+	boundary inside a tile) and the trig fused into the GEMM's store for every other shape (ragged: register staging;
+	d = 96 and the transposed outputs: LDS-DMA, K tiles of 32 floats); plain / biased / transposed"""
 	rng = np.random.RandomState(2 + n + d + m)
 	x, W = rng.uniform(0, 1, size=(n, d)).astype(np.float32), (rng.normal(size=(m, d)) / 8.0).astype(np.float32)
 	b = (2 * np.pi * rng.uniform(size=m)).astype(np.float32)
@@ -517,6 +518,34 @@ def test_rff_f32(L, n, d, m):
 	assert np.abs(outT.cpu().numpy() - ref.T).max() < 2e-5 * np.abs(ref).max()
 	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
 	assert np.abs(outT.cpu().numpy() - refb).max() < 2e-5 * np.abs(refb).max()
+
+
+def test_rff_f32_tile_kernel_matches_gemm_epilogue(L):
+	"""the two fp32 routes (stpy_tune key 9) on one tile-aligned problem, with a padded output leading dimension"""
+	n, d, m, ldo = 512, 64, 320, 384
+	rng = np.random.RandomState(11)
+	x, W = rng.uniform(-3, 3, size=(n, d)).astype(np.float32), (rng.normal(size=(m, d)) / 4.0).astype(np.float32)
+	b = (2 * np.pi * rng.uniform(size=m)).astype(np.float32)
+	lib = L.load()
+	xd, Wd, bd = dev(x, torch.float32), dev(W, torch.float32), dev(b, torch.float32)
+	scale = float(np.sqrt(2.0 / m))
+	outs = {}
+	assert lib.stpy_tune_get(9) == 1
+	try:
+		for route in (1, 0):
+			lib.stpy_tune(9, route)
+			for bias in (None, bd):
+				out = torch.full((n, ldo), 7.0, dtype=torch.float32, device="cuda:0")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, scale, L.ptr(out), ldo, 0, L.stream_ptr()), "rff")
+				outs[(route, bias is not None)] = out.cpu().numpy()
+	finally:
+		lib.stpy_tune(9, 1)
+	for biased in (False, True):
+		a, g = outs[(1, biased)], outs[(0, biased)]
+		assert np.all(a[:, m:] == 7.0) and np.all(g[:, m:] == 7.0)          # nothing written beyond column m
+		assert np.abs(a[:, :m] - g[:, :m]).max() < 1e-5 * np.abs(g[:, :m]).max()
+	ref = O.rff_embed(x.astype(np.float64), W.astype(np.float64), m)
+	assert np.abs(outs[(1, False)][:, :m] - ref).max() < 2e-5 * np.abs(ref).max()
 
 
 def test_error_reporting(L):
