@@ -93,10 +93,11 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* wor
                int32_t* info_dev, void* stream);
 
 /* B <- B L^-T for B: m x n row-major (rows = right-hand sides).  With B = K* (M x N) this is
- * V^T = (L^-1 K*^T)^T of the variance term, gauss_procc.py:378,392.  Left-looking over nb-wide
- * panels (nb = 0: chosen from m).  `work` (stpy_trsm_workspace_bytes, may be NULL) lets the long
- * panel products run as several K passes, which is what allows the latency-bound diagonal blocks
- * of the next panel to overlap them. */
+ * V^T = (L^-1 K*^T)^T of the variance term, gauss_procc.py:378,392.  From 2048 rows on: recursive
+ * halving of the column range (one long product per split, no workspace).  Fewer rows: panels of nb
+ * columns (nb = 0: library default), right-looking, or left-looking when n >= 32768 and `work`
+ * (stpy_trsm_workspace_bytes, may be NULL; 0 bytes when not needed) is given, which lets the long panel
+ * products run as several K passes so that the latency-bound diagonal blocks of the next panel overlap them. */
 int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb);
 int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
                        const void* winv, void* B, int64_t ldb, int nb, void* work, int64_t work_bytes, void* stream);

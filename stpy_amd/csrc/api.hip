@@ -129,6 +129,7 @@ int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (nb <= 0) nb = trsm_auto_nb(m);
+	if (g_trsm_right_looking >= 3 || (g_trsm_right_looking == 0 && m >= 2048)) return 0;      // recursive form: no workspace
 	if (n <= nb || (n < 32768 && g_trsm_right_looking != 2)) return 0;       // the right-looking sweep serves these sizes and needs none
 	return (int64_t)TRSM_MAX_PASSES * m * nb * (int64_t)(dtype == STPY_F32 ? 4 : 8);
 }

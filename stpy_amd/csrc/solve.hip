@@ -77,6 +77,27 @@ static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, con
 }
 
 
+// Recursive form (stpy_tune key 5 = 3): columns [c0, c0+w) split at h; solve the left part, subtract its
+// contribution from the right part in ONE product (m x (w-h) x h: long K and many tiles for all but the
+// deepest levels, half of all flops in the top-level product alone), solve the right part.  Everything is
+// in order on the caller's stream; the leaves are single 128-blocks.
+template <typename T>
+static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int64_t leaf)
+{
+	if (w <= leaf) return solve_panel<T>(m, n, c0, w, L, ldl, winv, B, ldb, st, upper_rhs);
+	int64_t h = IB;
+	while (h * 2 < w) h *= 2;                                 // largest power-of-two multiple of 128 below w
+	int rc = trsm_recursive<T>(m, n, c0, h, L, ldl, winv, B, ldb, st, upper_rhs, leaf);
+	if (rc) return rc;
+	const int64_t mr = upper_rhs ? ((c0 + h < m) ? c0 + h : m) : m;      // X[:, c0:c0+h) is zero from row c0+h on
+	{
+		ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mr * (double)(w - h) * (double)h, st);
+		rc = gemm_nt<T>(mr, w - h, h, B + c0, ldb, L + (c0 + h) * ldl + c0, ldl, B + c0 + h, ldb, (T*)nullptr, 0, 1, 0, st);
+		if (rc) return rc;
+	}
+	return trsm_recursive<T>(m, n, c0 + h, w - h, L, ldl, winv, B, ldb, st, upper_rhs, leaf);
+}
+
 // LEFT-looking between panels: panel p (columns [k, k+nb)) first receives every earlier panel's
 // contribution in ONE long-K product,  B[:, k:k+nb] -= X[:, 0:k) L[k:k+nb, 0:k)^T,  and is then solved.
 // The output of that product is read and written once per panel (a right-looking sweep re-reads
@@ -106,6 +127,13 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 	// is the faster form then (311 vs 335 ms at N = 65536, M = 4096; 299 ms with the workspace)
 	// ... and below n = 32768 in any case (28.1 vs 29.9 ms at n = 16384, 10.0 vs 11.0 at 8192, equal at 32768)
 	// (stpy_tune key 5: 1 forces the right-looking sweep, 2 the left-looking form at any n -- tests, A/B timing)
+	// Default from 2048 right-hand sides on: the recursive form (tools/trsm_sweep.py, fp64, M = 4096: 27.1 -> 24.7 ms at
+	// n = 16384, 83.9 -> 80.4 at 32768, 288 -> 284 at 65536; M = 10112: 705 -> 650 ms at 65536 = 66.9 TFLOP/s).  With fewer
+	// rows its lower levels have too few tiles per product and the panel forms below, which overlap the small kernels with
+	// a large product on a second stream (and split K), stay ahead (n = 65536, M = 1024: 97 vs 107 ms).
+	// (not for the triangular right-hand side of the inverse: value + gradient at N = 32768 0.615 s with the sweep, 0.677 s recursive)
+	if (g_trsm_right_looking >= 3 || (g_trsm_right_looking == 0 && m >= 2048 && !upper_rhs))
+		return trsm_recursive<T>(m, n, 0, n, L, ldl, winv, B, ldb, st, upper_rhs, g_trsm_right_looking >= 3 ? (int64_t)IB << (g_trsm_right_looking - 3) : 2 * IB);
 	if (g_trsm_right_looking == 1 || !work || (n < 32768 && g_trsm_right_looking != 2)) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs);
 	if (nb <= 0) nb = trsm_auto_nb(m);
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }

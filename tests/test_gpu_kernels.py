@@ -394,6 +394,13 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 		wk = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda:0")
 		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), wk.numel() * wk.element_size(), L.stream_ptr()), "trsm")
 		assert rel_err(Bw.cpu().numpy(), Xref) < 1e-11
+		# right-looking sweep and the recursive form (the default from 2048 rows on) with 128-, 256- and 512-column leaves
+		for alg in (1, 3, 4, 5):
+			lib.stpy_tune(5, alg)
+			assert alg == 1 or int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, nb)) == 0
+			Ba = dev(B)
+			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Ba), n, nb, None, 0, L.stream_ptr()), "trsm")
+			assert rel_err(Ba.cpu().numpy(), Xref) < 1e-11, alg
 	finally:
 		lib.stpy_tune(5, 0)
 	y = rng.normal(size=n)
@@ -492,6 +499,22 @@ def test_rff_transposed(L, dtype, tol):
 	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x, W, m, b=b)          # the reference's biased orientation is already (m, n)
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
+
+
+def test_trsm_many_rows_default_is_recursive(L):
+	"""m >= 2048 rows: the default block solve is the recursive form (no workspace), ragged n included"""
+	lib = L.load()
+	for n, m in ((1000, 2048), (1536, 2100)):
+		rng = np.random.RandomState(n + m)
+		K = spd(rng, n)
+		Ld, winv, info = run_potrf(L, K, 0)
+		assert info == 0
+		assert int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, 0)) == 0
+		B = rng.normal(size=(m, n))
+		Bd = dev(B)
+		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, 0, None, 0, L.stream_ptr()), "trsm")
+		Xref = sla.solve_triangular(np.linalg.cholesky(K), B.T, lower=True).T
+		assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 
 
 @pytest.mark.parametrize("n,d,m", [(300, 64, 512), (256, 64, 512), (384, 32, 256), (128, 96, 128), (128, 64, 192), (640, 32, 64)])
