@@ -197,7 +197,7 @@ void stpy_profile_enable(int enable);
  * 2 scalar diagonal-block kernel (0) · 3 / 4 pass depth and workgroup target of the left-looking block solve ·
  * 5 block-solve algorithm (0 auto, 1 right-looking, 2 left-looking) · 6 direct-to-VGPR GEMM from this many tiles (1; 0 never) ·
  * 7 diagonal block first below this order (8192) · 8 one-volley K = 128 kernel up to this many 64-tiles (768; 0 never) ·
- * 9 dedicated fp32 RFF tile kernel (1) */
+ * 9 fp32 RFF route (1: streaming kernel for large d = 64 shapes + tile kernel; 2: tile kernel only; 0: GEMM epilogue) */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */
 int stpy_tune_get(int key);

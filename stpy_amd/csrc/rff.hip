@@ -12,11 +12,13 @@
 //
 // Column layout quirk kept from the reference (embedding.py:236-239): without a bias the cos
 // half uses frequency rows 0..m/2-1 and the sin half uses the *other* rows m/2..m-1.
+#include <type_traits>
 #include "common.h"
 
 namespace stpy {
 
-int g_rff_tile = 1;             // dedicated fp32 tile kernel for d = 32 / 64 (stpy_tune key 9; 0 = always the GEMM epilogue)
+int g_rff_tile = 1;             // dedicated fp32 kernels (stpy_tune key 9): 1 = streaming kernel for large d = 64 shapes, tile kernel for
+                                // the other d = 32 / 64 shapes; 2 = tile kernel only; 0 = always the GEMM epilogue
 
 __global__ __launch_bounds__(256)
 void rff_trig_f64_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias, double scale)
@@ -145,6 +147,130 @@ void rff_tile_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* 
 	}
 }
 
+// ---- fp32, d = 64, large tile-aligned shapes (m % 512 == 0): persistent, barrier-free streaming kernel.
+// The phases of a tile in the kernel above are serial inside a workgroup and the co-resident workgroups run in
+// convoy, so MFMA, trig and memory time add up (tools/rff_ablate.py).  Here every WAVE is its own pipeline:
+//   * it keeps the A fragments of its 64 rows (the whole K = 64: 64 VGPRs) for a full sweep over its columns;
+//   * per 32-column tile it needs 8 float4 of W straight from L2 into VGPRs (prefetched one tile ahead) -- no LDS
+//     operand staging, no barrier, nothing shared between waves;
+//   * the trig + store of tile j-1 (results parked in registers) is interleaved, instruction by instruction, with
+//     the 128 MFMAs of tile j, so the VALU work rides in the MFMA issue shadow of the same wave;
+//   * the finished tile is turned through a wave-private 9 KiB LDS patch so each store writes full 128-byte lines.
+// Work split: blockIdx % 8 selects one eighth of the columns (with round-robin workgroup placement one XCD's L2
+// holds exactly that eighth of W), blockIdx / 8 strides over the 128-row blocks.
+__global__ __launch_bounds__(256, 2)
+void rff_stream_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                           float* __restrict__ out, int64_t ldo, int row_blocks, int cols_per_part, int half,
+                           const float* __restrict__ bias, float scale, int exp)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	constexpr int CLD = 36;
+	__shared__ __attribute__((aligned(16))) float smem[4 * 64 * CLD];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;     // wave-uniform: addresses below split into SGPR base + 32-bit lane offset
+	const int r16 = lane & 15, kq = lane >> 4;
+	float* const cw = smem + wave * (64 * CLD);
+	const int rr = lane >> 3, c4 = (lane & 7) * 4;
+	constexpr float INV_2PI = 0.15915494309189535f;
+	const int part = blockIdx.x & 7;
+	const int tiles = cols_per_part / 64;                 // 32-column tiles per wave and row block (the two wn waves alternate)
+	const int colp = part * cols_per_part;
+	const unsigned w_lane = (unsigned)r16 * (unsigned)ldw + 4u * kq;       // lane part of a W fragment address (elements)
+	const unsigned o_lane = (unsigned)rr * (unsigned)ldo + (unsigned)c4;   // lane part of an output address
+	const unsigned st_lane = (unsigned)(4 * kq) * CLD + r16;               // lane part of a staging write
+	const unsigned ld_lane = (unsigned)rr * CLD + c4;                      // lane part of a staging read
+
+	for (int rb = blockIdx.x >> 3; rb < row_blocks; rb += gridDim.x >> 3) {
+		const int64_t row0 = (int64_t)rb * 128 + wm * 64;
+		v4f a[4][4];
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) a[tm][g] = *(const v4f*)(x + (row0 + tm * 16 + r16) * ldx + 16 * g + 4 * kq) * INV_2PI;     // phases in revolutions
+
+		auto load_b = [&](v4f (&b)[2][4], int j) {
+			if ((exp & 4) && j > 1) return;
+			const float* const wb = W + (int64_t)(colp + (2 * j + wn) * 32) * ldw;          // uniform
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+				for (int g = 0; g < 4; ++g) b[tn][g] = *(const v4f*)((wb + (int64_t)(tn * 16) * ldw + 16 * g) + w_lane);
+		};
+		// MFMAs of tile j into `acc`, interleaved with trig + LDS staging of the previous tile's `res` (HAVE: there is one).
+		// The accumulation starts from the column's phase offset (b/2pi, -1/4 for sine columns): no separate add later.
+		auto tile = [&](auto have_tag, v4f (&acc)[4][2], const v4f (&b)[2][4], const v4f (&res)[4][2], int j) {
+			constexpr bool HAVE = decltype(have_tag)::value;
+			v4f offv[2];
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn) {
+				const int col = colp + (2 * j + wn) * 32 + tn * 16 + r16;
+				const float o = bias ? bias[col] * INV_2PI : (col < half ? 0.f : -0.25f);
+				offv[tn] = v4f{o, o, o, o};
+			}
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int step = g * 4 + c;               // 16 steps x 8 MFMAs; 2 result elements of the previous tile per step
+#pragma unroll
+					for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+						for (int tn = 0; tn < 2; ++tn)
+							acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][g][c], b[tn][g][c], step == 0 ? offv[tn] : acc[tm][tn], 0, 0, 0);
+					if constexpr (HAVE) {
+						const int tm = step >> 2, i = step & 3;
+#pragma unroll
+						for (int tn = 0; tn < 2; ++tn)
+							cw[st_lane + (unsigned)((tm * 16 + i) * CLD + tn * 16)] = scale * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(res[tm][tn][i]));
+#pragma unroll
+						for (int q = 0; q < 8; ++q) {         // one MFMA, then a slice of the VALU / LDS work, eight times
+							__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+							__builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+							if (q == 3 || q == 7) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+		};
+		auto finish = [&](const v4f (&res)[4][2]) {        // the last tile of a sweep: nothing left to hide it under
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int tn = 0; tn < 2; ++tn)
+						cw[st_lane + (unsigned)((tm * 16 + i) * CLD + tn * 16)] = scale * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(res[tm][tn][i]));
+		};
+		auto flush = [&](int j) {                           // wave-private patch -> eight full-line stores per instruction
+			if ((exp & 1) && scale != 12345.f) return;
+			float* const ob = out + row0 * ldo + (colp + (2 * j + wn) * 32);             // uniform
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				const v4f v = *(const v4f*)&cw[ld_lane + (unsigned)(8 * q * CLD)];
+				__builtin_nontemporal_store(v, (v4f*)((ob + (int64_t)(8 * q) * ldo) + o_lane));
+			}
+		};
+
+		// two tiles per trip (tiles is even) so that accumulator / result and the two W buffers swap roles without copies
+		v4f b0[2][4], b1[2][4], acc0[4][2], acc1[4][2];
+		load_b(b0, 0);
+		for (int j = 0; j < tiles; j += 2) {
+			load_b(b1, j + 1);
+			if (j == 0) {
+				tile(std::false_type{}, acc0, b0, acc1, j);
+			} else {
+				tile(std::true_type{}, acc0, b0, acc1, j);           // tile j; finishes tile j-1
+				flush(j - 1);
+			}
+			load_b(b0, j + 2 < tiles ? j + 2 : j);
+			tile(std::true_type{}, acc1, b1, acc0, j + 1);           // tile j+1; finishes tile j
+			flush(j);
+		}
+		finish(acc1);
+		flush(tiles - 1);
+	}
+}
+
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
               const T* bias, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
@@ -155,6 +281,14 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 {
 	if (n <= 0 || m <= 0) return 0;
 	if (m % 2 != 0) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
+	if (g_rff_tile >= 1 && g_rff_tile != 2 && !transposed && d == 64 && n % 128 == 0 && m % 1024 == 0 && n >= 8192 && ldw < ((int64_t)1 << 27) && ldo < ((int64_t)1 << 28) && ldx % 4 == 0 && ldw % 4 == 0 &&
+	    ldo % 4 == 0 && (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out) & 15) == 0 && n / 128 < (int64_t)INT32_MAX && m < (int64_t)INT32_MAX) {
+		const int row_blocks = (int)(n / 128);
+		int wgs = 512;                                                   // two per CU; a multiple of eight (one column part per XCD)
+		if (wgs > 8 * row_blocks) wgs = 8 * row_blocks;
+		hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
+		return check_launch("rff_stream_f32");
+	}
 	if (g_rff_tile && !transposed && (d == 32 || d == 64) && n % 128 == 0 && m % 64 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
 	    (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0 && (n / 128) * (m / 64) < (int64_t)INT32_MAX && m < (int64_t)INT32_MAX) {
 		const int col_tiles = (int)(m / 64);

@@ -88,7 +88,13 @@ def test_rff_tile_kernel_fits_three_per_cu(tmp_path):
 	"""rff_tile_f32_kernel relies on three co-resident workgroups per CU: <= 53 KiB of LDS, <= 168 VGPRs, no scratch."""
 	out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", os.path.join(CSRC, "rff.hip"),
 						  "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True).stderr
-	blocks = [b for b in re.split(r"remark: Function Name: ", out)[1:] if "rff_tile_f32_kernel" in b.split()[0]]
+	allb = re.split(r"remark: Function Name: ", out)[1:]
+	stream = [b for b in allb if "rff_stream_f32_kernel" in b.split()[0]]
+	assert len(stream) == 1          # persistent streaming kernel: two waves per SIMD (<= 256 VGPRs), nothing in scratch
+	assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", stream[0]).group(1)) == 0
+	assert int(re.search(r"\bVGPRs: (\d+)", stream[0]).group(1)) <= 256
+	assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", stream[0]).group(1)) >= 2
+	blocks = [b for b in allb if "rff_tile_f32_kernel" in b.split()[0]]
 	assert len(blocks) == 2
 	for b in blocks:
 		assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0

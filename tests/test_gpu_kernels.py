@@ -571,6 +571,36 @@ def test_rff_f32_tile_kernel_matches_gemm_epilogue(L):
 	assert np.abs(outs[(1, False)][:, :m] - ref).max() < 2e-5 * np.abs(ref).max()
 
 
+def test_rff_f32_streaming_kernel(L):
+	"""n >= 8192, m % 1024 == 0, d = 64: the persistent streaming kernel (stpy_tune key 9 = 1) against the tile kernel (2) and
+	the GEMM epilogue (0), plain and biased, with a row count that leaves the last stride of row blocks partly idle"""
+	n, d, m = 8192 + 3 * 128, 64, 2048
+	rng = np.random.RandomState(5)
+	x, W = rng.uniform(-2, 2, size=(n, d)).astype(np.float32), (rng.normal(size=(m, d)) / 4.0).astype(np.float32)
+	b = (2 * np.pi * rng.uniform(size=m)).astype(np.float32)
+	lib = L.load()
+	xd, Wd, bd = dev(x, torch.float32), dev(W, torch.float32), dev(b, torch.float32)
+	scale = float(np.sqrt(2.0 / m))
+	outs = {}
+	try:
+		for route in (1, 2, 0):
+			lib.stpy_tune(9, route)
+			for bias in (None, bd):
+				out = torch.full((n, m), 7.0, dtype=torch.float32, device="cuda:0")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+				outs[(route, bias is not None)] = out.cpu().numpy()
+	finally:
+		lib.stpy_tune(9, 1)
+	ref = O.rff_embed(x[:512].astype(np.float64), W.astype(np.float64), m)
+	refb = O.rff_embed(x[:512].astype(np.float64), W.astype(np.float64), m, b=b.astype(np.float64)).T
+	for biased, r in ((False, ref), (True, refb)):
+		a = outs[(1, biased)]
+		assert np.abs(a).max() <= scale * (1 + 1e-6)                  # every element written (the fill value was 7)
+		for other in (2, 0):
+			assert np.abs(a - outs[(other, biased)]).max() < 1e-5 * scale
+		assert np.abs(a[:512] - r).max() < 2e-5 * np.abs(r).max()
+
+
 def test_error_reporting(L):
 	lib = L.load()
 	WORK = None

@@ -1,0 +1,20 @@
+import sys, time, math
+import torch
+sys.path.insert(0, ".")
+from stpy_amd import _lib as L
+lib = L.load()
+dev = torch.device("cuda:0")
+n, d, m = 262144, 64, 32768
+x = torch.rand(n, d, dtype=torch.float32, device=dev)
+W = torch.randn(m, d, dtype=torch.float32, device=dev) / 8
+out = torch.empty(n, m, dtype=torch.float32, device=dev)
+res = {}
+for rnd in range(4):
+	for route in (1, 2, 0):
+		lib.stpy_tune(9, route)
+		torch.cuda.synchronize(); t0 = time.perf_counter()
+		L.check(lib.stpy_rff_embed(L.F32, L.ptr(x), n, d, d, L.ptr(W), d, m, None, math.sqrt(2.0 / m), L.ptr(out), m, 0, L.stream_ptr()), "rff")
+		torch.cuda.synchronize(); res.setdefault(route, []).append(time.perf_counter() - t0)
+lib.stpy_tune(9, 1)
+for route, name in ((1, "streaming"), (2, "tile"), (0, "gemm epilogue")):
+	print("%-14s %s ms" % (name, " ".join("%.2f" % (t * 1e3) for t in res[route])))
