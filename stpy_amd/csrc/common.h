@@ -52,6 +52,12 @@ template <> struct Mfma<double> {
 	static __device__ __forceinline__ v4 mma(double a, double b, v4 c) {
 		return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 	}
+	// c - a b: the f64 MFMA encodes neg:[a,b,c] in the blgp field, so the subtraction is free (no VALU negation
+	// in the K loop, no VALU -> MFMA wait states)
+	static constexpr bool HAS_NEG = true;
+	static __device__ __forceinline__ v4 mms(double a, double b, v4 c) {
+		return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+	}
 	static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) + 4 * i; }
 };
 template <> struct Mfma<float> {
@@ -59,6 +65,10 @@ template <> struct Mfma<float> {
 	typedef float v2 __attribute__((ext_vector_type(2)));
 	static __device__ __forceinline__ v4 mma(float a, float b, v4 c) {
 		return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+	}
+	static constexpr bool HAS_NEG = false;           // (blgp is a lane-group broadcast pattern for f32, not a negation)
+	static __device__ __forceinline__ v4 mms(float a, float b, v4 c) {
+		return __builtin_amdgcn_mfma_f32_16x16x4f32(-a, b, c, 0, 0, 0);
 	}
 	static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) * 4 + i; }
 };

@@ -611,32 +611,37 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
 
 	// ---- B through LDS-DMA: wave w moves rows [32w, 32w+32), 8 rows (1 KiB) per piece
-	const T* dsrc[4];
+	// Every global address below is a wave-uniform 64-bit base in SGPRs (advanced on the scalar unit) plus a 32-bit
+	// lane offset that never changes: no vector address arithmetic in the K loop (VALU issue is not hidden under the
+	// MFMAs of the same SIMD).  Piece i of a wave holds rows r = 32 wave + 8 i + (lane >> 3); the swizzle
+	// f(r) has ((r >> 1) & 3) from the lane and (r >> 3) & 1 = i & 1, so two lane offsets serve the four pieces.
+	const T* const bbase = p.B + (int64_t)(col0 + wave * 32) * p.ldb + kbeg;           // uniform
+	unsigned blane[2];
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int r = wave * 32 + i * 8 + (lane >> 3);
-		const int f = (((r >> 1) & 3) << 1) | ((r >> 3) & 1);
-		dsrc[i] = p.B + (int64_t)(col0 + r) * p.ldb + kbeg + ((lane & 7) ^ f) * CH;
+	for (int par = 0; par < 2; ++par) {
+		const int rl = lane >> 3;
+		const int f = (((rl >> 1) & 3) << 1) | par;
+		blane[par] = ((unsigned)rl * (unsigned)p.ldb + (unsigned)(((lane & 7) ^ f) * CH)) * (unsigned)sizeof(T);
 	}
-	auto dma_one = [&](const T* gsrc, unsigned laddr) {
+	auto dma_one = [&](const T* gbase, unsigned voff, unsigned laddr) {
 		unsigned keep;
-		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-		             : "=&s"(keep) : "v"(gsrc), "s"(laddr) : "memory");
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(laddr) : "memory");
 	};
 	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
 	auto dma_tile = [&](int buf, int k0) {
 		const unsigned base = lds0 + (unsigned)(buf * BN + wave * 32) * 128u;       // 128-byte rows
 #pragma unroll
-		for (int i = 0; i < 4; ++i) dma_one(dsrc[i] + k0, base + i * 8 * 128u);
+		for (int i = 0; i < 4; ++i) dma_one(bbase + (int64_t)(i * 8) * p.ldb + k0, blane[i & 1], base + i * 8 * 128u);
 	};
 
 	// ---- A straight into registers: uniform row-tile base + one 32-bit lane offset
 	const T* const abase = p.A + (int64_t)(row0 + wm * 64) * p.lda + kbeg;
-	const unsigned alane = (unsigned)r16 * (unsigned)p.lda + (unsigned)g * 2 * CH;  // elements: chunk 2g of the row
+	const unsigned alane = ((unsigned)r16 * (unsigned)p.lda + (unsigned)g * 2 * CH) * (unsigned)sizeof(T);  // bytes: chunk 2g of the row
 	d2 fa[4][2];
 	auto lda_frag = [&](int tm, int h, int k0) {
-		const T* ptr = abase + (int64_t)tm * 16 * p.lda + (alane + (unsigned)k0 + (unsigned)h * CH);
-		asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fa[tm][h]) : "v"(ptr) : "memory");
+		const T* const ub = abase + (int64_t)tm * 16 * p.lda + k0 + h * CH;        // uniform
+		asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(fa[tm][h]) : "v"(alane), "s"(ub) : "memory");
 	};
 	auto wait_frag = [&](int tm, int h) { asm volatile("s_waitcnt vmcnt(11)" : "+v"(fa[tm][h]) :: "memory"); };
 
@@ -677,7 +682,7 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 			d2 fb[4];
 			const T* bs = smem + buf * BN * BK + boff + ((2 * g + h) ^ fsw) * CH;
 #pragma unroll
-			for (int t = 0; t < 4; ++t) { fb[t] = *(const d2*)(bs + t * 16 * BK); if (SUB) fb[t] = -fb[t]; }
+			for (int t = 0; t < 4; ++t) { fb[t] = *(const d2*)(bs + t * 16 * BK); if (SUB && !MM::HAS_NEG) fb[t] = -fb[t]; }
 #pragma unroll
 			for (int tm = 0; tm < 4; ++tm) {
 				if (!LAST) wait_frag(tm, h);
@@ -691,7 +696,7 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 				for (int s = 0; s < CH; ++s)
 #pragma unroll
 					for (int tn = 0; tn < 4; ++tn)
-						acc[tm][tn] = MM::mma(fa[tm][h][s], fb[tn][s], acc[tm][tn]);
+						acc[tm][tn] = (SUB && MM::HAS_NEG) ? MM::mms(fa[tm][h][s], fb[tn][s], acc[tm][tn]) : MM::mma(fa[tm][h][s], fb[tn][s], acc[tm][tn]);
 				if (!LAST) lda_frag(tm, h, knext);            // refill in place: every MFMA that reads fa[tm][h] has been issued
 			}
 		}
@@ -1007,7 +1012,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	}
 	{
 		const int64_t dtv_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n * p.ksplit;
-		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && k >= g_gemm_dtv_min_k * (int)(8 / sizeof(T))) {
+		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && lda < (1 << 24) && ldb < (1 << 24) && k >= g_gemm_dtv_min_k * (int)(8 / sizeof(T))) {
 			if (mode == 1 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, true>), grid, block, 0, st, p);
 			else hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, false>), grid, block, 0, st, p);
 			if (p.ksplit > 1) {
