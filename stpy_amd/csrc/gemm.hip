@@ -667,6 +667,12 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 			for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = SUB ? crow[tn * 16] : T(0);
 		}
 	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+	if constexpr (SUB && !MM::HAS_NEG) {         // f32 has no negating MFMA: accumulate A B^T - C and flip the sign once at the store
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = -acc[tm][tn];
+	}
 	__syncthreads();
 
 	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);
@@ -682,7 +688,7 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 			d2 fb[4];
 			const T* bs = smem + buf * BN * BK + boff + ((2 * g + h) ^ fsw) * CH;
 #pragma unroll
-			for (int t = 0; t < 4; ++t) { fb[t] = *(const d2*)(bs + t * 16 * BK); if (SUB && !MM::HAS_NEG) fb[t] = -fb[t]; }
+			for (int t = 0; t < 4; ++t) fb[t] = *(const d2*)(bs + t * 16 * BK);
 #pragma unroll
 			for (int tm = 0; tm < 4; ++tm) {
 				if (!LAST) wait_frag(tm, h);
@@ -711,6 +717,12 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 	// C may alias A (the block solve multiplies a row block by an inverse diagonal block in place): every wave of the
 	// workgroup has its last A fragments in registers (vmcnt(0) above) before anyone stores
 	__syncthreads();
+	if constexpr (SUB && !MM::HAS_NEG) {
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = -acc[tm][tn];
+	}
 
 #pragma unroll
 	for (int tm = 0; tm < 4; ++tm)
