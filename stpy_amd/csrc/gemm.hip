@@ -607,6 +607,16 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 	const int kbeg = p.kskip ? row0 : split * p.kchunk;
 	const int kend = p.ksplit > 1 ? min(p.k, kbeg + p.kchunk) : p.k;
 	const int KT = (kend - kbeg) / BK;
+	// desynchronise the two workgroups of a CU once: started together they share the MFMA pipe, finish together and then
+	// both sit in their C-tile store / next C-tile load at the same time with the pipe idle; an offset of at least that
+	// memory phase persists from round to round (each slot is refilled when its workgroup ends)
+	if (p.stagger > 0 && b < 512) {
+		const unsigned hwid = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_REG_HW_ID[3:0] = wave slot in its SIMD
+		if (hwid & 1u) {
+			const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+			while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(32);
+		}
+	}
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
 
@@ -1004,7 +1014,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	{
 		const int64_t real_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n;
 		const int64_t kt = (k + KTile<T>::BK - 1) / KTile<T>::BK;
-		p.stagger = (g_gemm_stagger && real_tiles >= 8 * 512) ? (int)(kt * 64 * 64) : 0;     // kt * 64 MFMAs * 64 cycles = half of a two-wave tile
+		p.stagger = (g_gemm_stagger && real_tiles >= 8 * 512) ? (g_gemm_stagger > 1 ? g_gemm_stagger : (int)(kt * 64 * 64)) : 0;     // 1: kt * 64 MFMAs * 64 cycles = half of a two-wave tile; > 1: that many cycles
 	}
 	constexpr int CH = 16 / sizeof(T);
 	const bool aligned = (m % BM == 0) && (n % BN == 0) && (k % KTile<T>::BK == 0) && (lda % CH == 0) && (ldb % CH == 0) &&
