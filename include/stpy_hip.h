@@ -193,7 +193,7 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
  */
 void stpy_profile_enable(int enable);
 /* A/B switches used by tools/ (process-wide, not part of the data path's contract):
- * 0 first-round workgroup stagger of the GEMM (0 off; 1 half a tile; > 1 that many cycles) · 1 phase-ablation bits for timing experiments (0) ·
+ * 0 first-round workgroup stagger of the GEMM (40000 cycles; 0 off; 1 half a tile) · 1 phase-ablation bits for timing experiments (0) ·
  * 2 scalar diagonal-block kernel (0) · 3 / 4 pass depth and workgroup target of the left-looking block solve ·
  * 5 block-solve algorithm (0 auto, 1 right-looking, 2 left-looking) · 6 direct-to-VGPR GEMM from this many tiles (1; 0 never) ·
  * 7 diagonal block first below this order (8192) · 8 one-volley K = 128 kernel up to this many 64-tiles (768; 0 never) ·

@@ -32,7 +32,7 @@ constexpr int BM = 128, BN = 128, NTHREADS = 256;
 // K tile: one 128-byte row per operand row (16 doubles / 32 floats), so both types share the LDS byte layout,
 // the LDS-DMA pieces and the swizzle
 template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof(T); };
-int g_gemm_stagger = 0;
+int g_gemm_stagger = 40000;    // first-round offset (cycles) between the two workgroups of a CU in launches of >= 4096 tiles (stpy_tune key 0; 0 = off, 1 = half a tile)
 int g_gemm_dtv = 1;            // A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
 int g_gemm_dtv_min_k = 64;
 int g_gemm_k128 = 768;           // K = 128 products with at most this many 64 x 64 tiles take the one-volley kernel (stpy_tune key 8; 0 = never)

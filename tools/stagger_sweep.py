@@ -23,4 +23,4 @@ for k in (256, 512, 1024, 2048):
 			res.setdefault(v, []).append(min(ts))
 	fl = 2.0 * n * n * k * (0.5 + 64.0 / n)
 	print("k %5d: " % k + "  ".join("[%d] %.3f ms %.1f TF" % (v, min(r) * 1e3, fl / min(r) / 1e12) for v, r in res.items()), flush=True)
-lib.stpy_tune(0, 0)
+lib.stpy_tune(0, 40000)
