@@ -184,7 +184,7 @@ def main():
 			"ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": False,
 			"scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: %s backend, ranks share one GPU)" % backend,
 			"config": {"workload": "GaussianProcess.fit_gp + mean_std, SE kernel gamma=sqrt(d), s=0.1, N=%d train, M=%d test, d=%d, fp64" % (n, m, d),
-					   "n": n, "m": m, "d": d, "nb": args.nb or ("distribution block %d" % gp.NB if dist_path else "potrf 1024, trsm 512 (library defaults)"),
+					   "n": n, "m": m, "d": d, "nb": args.nb or ("distribution block %d" % gp.NB if dist_path else "potrf panels 1024, recursive block solve (library defaults)"),
 					   "parallelism": "2-D block-cyclic over %d GPU%s" % (world, "s" if world > 1 else " (forced: functional check of the distributed code path)") if dist_path else "single GPU"},
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),
