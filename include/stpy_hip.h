@@ -13,10 +13,21 @@
  *     shipped host code); matrices are row-major with an explicit leading dimension in ELEMENTS;
  *   - dtype: 0 = float64, 1 = float32 (all operands of one call share it);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
- *   - no allocation, no ownership transfer, no global mutable state besides a thread-local
- *     last-error string; workspaces are sized by the *_workspace_bytes queries and passed with their size
- *     (`work_bytes`): a workspace smaller than the query's answer for the same arguments is refused (-20) instead
- *     of being overrun;
+ *   - no allocation of data, no ownership transfer; workspaces are sized by the *_workspace_bytes queries and
+ *     passed with their size (`work_bytes`), the inverse-diagonal-block array `winv` with its element count
+ *     (`winv_elems`): a buffer smaller than the query's answer for the same arguments is refused (-20 / -21)
+ *     instead of being overrun;
+ *   - state kept by the library, all of it documented here:
+ *       * a thread-local last-error string;
+ *       * per (device, caller stream): one high-priority side stream + three events, created on the first
+ *         stpy_potrf / stpy_trsm_right_lt call on that stream and kept for the life of the process (the panel
+ *         look-ahead).  Host threads that drive DIFFERENT streams may call concurrently; calls that share a
+ *         stream must be issued by one thread at a time (they are ordered by the stream, like any HIP work);
+ *       * the launch profiler's record table (stpy_profile_*), guarded by a mutex, off by default;
+ *       * the stpy_tune A/B switches: process-wide integers read at launch time.  They exist for tools/ timing
+ *         experiments, are never written by the shipped host code, and must not be changed while another
+ *         thread is inside the library.  Behaviour a caller may legitimately want per call is a `flags`
+ *         argument instead (STPY_FLAG_*);
  *   - return value: 0 = ok, <0 = invalid argument (-(index of the argument), 1-based) or
  *     -1000-hipError for a failed launch; numerical failure of the factorisation is reported
  *     through the device word `info_dev` (0 = ok, j>0 = leading minor j not positive definite),
@@ -44,6 +55,14 @@ enum {
 	STPY_K_LINEAR = 4,    /* kappa * <b_j, a_i> + offset              kernels.py:300-320                 */
 	STPY_K_POLY = 5       /* kappa * (<b_j, a_i> + offset)^p          kernels.py:744-761 (offset = 1 there);
 	                         the degree p (1..64) rides above the family byte: kind = STPY_K_POLY | (p << 8) */
+};
+
+/* per-call flags of stpy_potrf / stpy_trsm_right_lt */
+enum {
+	STPY_FLAG_BESIDE_UPDATE = 1   /* the call is enqueued while another stream's trailing update occupies the chip
+	                                 (multi-GPU panel look-ahead): its small K = 128 products take the 32 KiB-LDS
+	                                 kernels that fit on a CU beside one update workgroup, not the 128 KiB one-volley
+	                                 kernel that would wait for a whole CU to drain */
 };
 
 /* how a kernel evaluation is combined into `out` -- the + and * kernel algebra of kernels.py:146-157 */
@@ -82,15 +101,15 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,
  * Blocked right-looking Cholesky, A = L L^T in place in the lower triangle (the strict upper
  * triangle is scratch).  Replaces torch.linalg.cholesky (estimator.py:35) and stands in for
  * lstsq / lu_factor / slogdet (gauss_procc.py:370-378, :634).
- * winv: ceil(n/128) blocks of 128x128 elements; receives inverse(L_cc) of every 128x128
- *       diagonal block (reused by the triangular solves below).
+ * winv: ceil(n/128) blocks of 128x128 elements (winv_elems >= stpy_potrf_winv_elems(n), else -21); receives
+ *       inverse(L_cc) of every 128x128 diagonal block (reused by the triangular solves below).
  * work: stpy_potrf_workspace_bytes(dtype, n, nb) bytes.   nb: outer panel width, multiple of 128
  *       (0 = library default).   info_dev: device int32.
  */
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb);
 int64_t stpy_potrf_winv_elems(int64_t n);
-int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int64_t work_bytes, int nb,
-               int32_t* info_dev, void* stream);
+int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, int64_t winv_elems,
+               void* work, int64_t work_bytes, int nb, int flags, int32_t* info_dev, void* stream);
 
 /* B <- B L^-T for B: m x n row-major (rows = right-hand sides).  With B = K* (M x N) this is
  * V^T = (L^-1 K*^T)^T of the variance term, gauss_procc.py:378,392.  From 2048 rows on: recursive
@@ -100,7 +119,8 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* wor
  * products run as several K passes so that the latency-bound diagonal blocks of the next panel overlap them. */
 int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb);
 int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl,
-                       const void* winv, void* B, int64_t ldb, int nb, void* work, int64_t work_bytes, void* stream);
+                       const void* winv, int64_t winv_elems, void* B, int64_t ldb, int nb, int flags,
+                       void* work, int64_t work_bytes, void* stream);
 
 /*
  * Gradient of the evidence (estimator.py:156-190 drives it through
@@ -108,21 +128,23 @@ int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t l
  *
  * stpy_potri: Kinv (n x n, lower triangle written) <- (L L^T)^-1 from the factor; work: n x n
  *   elements of scratch (receives L^-T).  2 n^3/3 flop on the MFMA GEMM.
- * stpy_lml_weight: H <- (weight * H - alpha alpha^T) o F in place, H holding the full symmetric
- *   K^-1 on entry; F_ij is the factor of d k(x_i,x_j) / d lengthscale_m = F_ij u_m^2 / lengthscale_m
+ * stpy_lml_weight: H <- (weight * Kinv - alpha alpha^T) o F, Kinv the full symmetric K^-1 (n x n; Kinv == NULL or
+ *   Kinv == H: in place over H; otherwise Kinv is only read, so several kernel terms share one inverse without a
+ *   copy); F_ij is the factor of d k(x_i,x_j) / d lengthscale_m = F_ij u_m^2 / lengthscale_m
  *   (u = scaled coordinate difference) for the kernel family `kind` (SE, MATERN12/32/52).
  *   work: stpy_gram_workspace_bytes(dtype, n, n, d).  The per-coordinate sums sum_ij H_ij u_m^2 then
  *   follow from H [Xs | 1] (one stpy_gemm_nt) -- see stpy_amd/continuous_processes/gauss_procc.py.
  */
-int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv,
+int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, int64_t winv_elems,
                void* Kinv, int64_t ldk, void* work, int64_t work_bytes, void* stream);
 int stpy_lml_weight(int kind, int dtype, const void* x, int64_t n, int64_t ldx, int d,
                     const int32_t* cols, const void* inv_ls, double kappa, double weight,
-                    const void* alpha, void* H, int64_t ldh, void* work, int64_t work_bytes, void* stream);
+                    const void* alpha, const void* Kinv, int64_t ldk, void* H, int64_t ldh,
+                    void* work, int64_t work_bytes, void* stream);
 
 /* out = L^-1 y (trans = 0) or out = L^-T y (trans = 1); the two together are cholesky_solve,
  * estimator.py:37.  y is used as scratch (destroyed); out must not alias y. */
-int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* y,
+int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, int64_t winv_elems, void* y,
               void* out, int trans, void* stream);
 
 /* mu[i] = <X_i, z>,  sigma[i] = sqrt(kdiag[i] - <X_i, X_i>)   (X = K* L^-T, z = L^-1 y)
@@ -131,6 +153,17 @@ int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv
  * sums of a column-sharded X, reduced across ranks by the caller).  mu or sigma may be NULL. */
 int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, const void* z,
                  const void* kdiag, void* mu, void* sigma, int clamp, void* stream);
+
+/* The same epilogue when X is sharded by columns across ranks (multi-GPU): stpy_predict(clamp = 2) yields the local
+ * partial sums, the caller all-reduces them, and this finishes in place:  mu[i] *= scale,
+ * sigma[i] = sqrt(kdiag[i] - scale * sumsq[i])  (scale = 1 / replicas that took part in the sum).  mu / sigma may be NULL. */
+int stpy_predict_finish(int dtype, int64_t m, void* mu, const void* sumsq, const void* kdiag, double scale,
+                        void* sigma, int clamp, void* stream);
+
+/* out (op)= src elementwise on an m x n window, then + diag_add on the diagonal: the + / * algebra of kernels.py:146-157
+ * for an item that was first summed into scratch (combine: STPY_OUT_SET / _ADD / _MUL). */
+int stpy_combine(int dtype, int64_t m, int64_t n, void* out, int64_t ldo, const void* src, int64_t lds,
+                 int combine, double diag_add, void* stream);
 
 /* out2[0] = sum_i log L_ii,  out2[1] = z^T z   (estimator.py:36-38, gauss_procc.py:634-636) */
 int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const void* z,
@@ -177,11 +210,15 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
  *                                  scale * sin(<W_j, x_i>)  for j >= m/2
  *   bias != NULL: out[i*ldo + j] = scale * cos(<W_j, x_i> + bias[j])
  * x: n x ldx (d columns used), W: m x ldw, out: n x m;  scale = sqrt(2/m) * sqrt(kappa).
+ * feat_scale != NULL: feature j is additionally multiplied by feat_scale[j] (m elements of `dtype`) -- the sqrt of the
+ *   quadrature weights of QuadratureEmbedding.embed / HermiteEmbedding (embedding.py:450-466, :573-602), which pairs
+ *   cos and sin of the SAME node: pass W stacked twice and scale = sqrt(kappa).  An odd m is accepted with a bias only
+ *   (cosine-only grids pass a zero bias).
  * transposed != 0 writes Phi^T instead (out: m x n, out[j*ldo + i]) -- the "row x K" operand the
  * feature-space normal equations Phi^T Phi need (kernelized_features.py:236-240).
  */
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
-                   const void* W, int64_t ldw, int64_t m, const void* bias, double scale,
+                   const void* W, int64_t ldw, int64_t m, const void* bias, const void* feat_scale, double scale,
                    void* out, int64_t ldo, int transposed, void* stream);
 
 /*
@@ -192,7 +229,8 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
  * (ms), the summed algorithmic flops and the number of launches of that tag.
  */
 void stpy_profile_enable(int enable);
-/* A/B switches used by tools/ (process-wide, not part of the data path's contract):
+/* A/B switches used by tools/ (process-wide; see "state kept by the library" at the top -- the shipped host code never
+ * writes them):
  * 0 first-round workgroup stagger of the GEMM (40000 cycles; 0 off; 1 half a tile) · 1 phase-ablation bits for timing experiments (0) ·
  * 2 scalar diagonal-block kernel (0) · 3 / 4 pass depth and workgroup target of the left-looking block solve ·
  * 5 block-solve algorithm (0 auto, 1 right-looking, 2 left-looking) · 6 direct-to-VGPR GEMM from this many tiles (1; 0 never) ·

@@ -18,6 +18,7 @@ F64, F32 = 0, 1
 K_SE, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR, K_POLY = 0, 1, 2, 3, 4, 5
 OUT_SET, OUT_ADD, OUT_MUL = 0, 1, 2
 IB = 128
+FLAG_BESIDE_UPDATE = 1
 
 _c = ctypes
 _vp, _i64, _i32, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_double
@@ -31,12 +32,14 @@ SIGNATURES = {
 	"stpy_gram_diag": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _i32, _vp, _vp]),
 	"stpy_potrf_workspace_bytes": (_i64, [_i32, _i64, _i32]),
 	"stpy_potrf_winv_elems": (_i64, [_i64]),
-	"stpy_potrf": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp]),
+	"stpy_potrf": (_i32, [_i32, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
 	"stpy_trsm_workspace_bytes": (_i64, [_i32, _i64, _i64, _i32]),
-	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
-	"stpy_potri": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
-	"stpy_lml_weight": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp, _i64, _vp]),
-	"stpy_trsv": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+	"stpy_trsm_right_lt": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
+	"stpy_potri": (_i32, [_i32, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+	"stpy_lml_weight": (_i32, [_i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+	"stpy_predict_finish": (_i32, [_i32, _i64, _vp, _vp, _vp, _dbl, _vp, _i32, _vp]),
+	"stpy_combine": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _dbl, _vp]),
+	"stpy_trsv": (_i32, [_i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),
 	"stpy_predict": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
 	"stpy_logdet_quad": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp]),
 	"stpy_gemm_nt": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
@@ -44,7 +47,7 @@ SIGNATURES = {
 	"stpy_gemm_nt_splitk": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
 	"stpy_gemm_nt_bc": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 	"stpy_symmetrize_lower": (_i32, [_i32, _i64, _vp, _i64, _vp]),
-	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _dbl, _vp, _i64, _i32, _vp]),
+	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _dbl, _vp, _i64, _i32, _vp]),
 	"stpy_profile_enable": (None, [_i32]),
 	"stpy_profile_read_union": (_i32, [_i32, _c.POINTER(_dbl), _c.POINTER(_dbl), _c.POINTER(_i64)]),
 	"stpy_tune": (None, [_i32, _i32]),

@@ -188,7 +188,7 @@ class GaussianProcess:
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=xd.dtype, device=xd.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, n, self.nb)),), dtype=torch.uint8, device=xd.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
-		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb, _lib.ptr(info), _lib.stream_ptr())
+		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr())
 		_lib.check(rc, "stpy_potrf")
 		bad = int(info.item())          # the one synchronisation of a fit
 		del work
@@ -202,7 +202,7 @@ class GaussianProcess:
 		scratch = torch.zeros((L.shape[0],), dtype=L.dtype, device=L.device)
 		scratch[:yd.numel()] = yd.reshape(-1)
 		z = torch.empty_like(scratch)
-		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(z), 0,
+		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(z), 0,
 								 _lib.stream_ptr()), "stpy_trsv")
 		return z
 
@@ -211,7 +211,7 @@ class GaussianProcess:
 		lib = _lib.load()
 		scratch = z.clone()
 		alpha = torch.empty_like(scratch)
-		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(alpha), 1,
+		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(alpha), 1,
 								 _lib.stream_ptr()), "stpy_trsv")
 		return alpha
 
@@ -239,14 +239,34 @@ class GaussianProcess:
 		self._Sigma = Sigma
 		self._xd = _lib.to_device(x)
 		self._yd = _lib.to_device(y, self._xd.dtype).reshape(-1, 1)
+		# not fitted until the new factor exists: a refit that fails (not positive definite, out of memory) leaves an
+		# object that takes the prior branch instead of one that reports fitted=True with no factor behind it
+		self.fitted = False
 		self._L = self._winv = self._z = self._alpha_cache = None       # release the previous factor before allocating the next
 		self._L, self._winv = self._factor(self._xd, None, Sigma)
 		self._z = self._forward_y(self._L, self._winv, self._yd)
 		# A = K^-1 y is part of the fitted state the reference leaves behind (gauss_procc.py:376): computed
 		# eagerly even though mean_std itself only needs z
 		self._alpha_cache = self._backward_z(self._L, self._winv, self._z)[:self.n]
+		self._factor_key = self._hyper_key(self.kernel_object)
 		self.fitted = True
 		return None
+
+	def _hyper_key(self, kernel):
+		"""What the resident factor was built from: the noise level and every stored kernel parameter, by value.
+		log_marginal re-uses the factor only while this is unchanged (the reference rebuilds K from the CURRENT
+		self.s / params_dict on every call, gauss_procc.py:631-638)."""
+		def freeze(v):
+			if torch.is_tensor(v):
+				return ("t", tuple(v.detach().reshape(-1).tolist()))
+			if isinstance(v, np.ndarray):
+				return ("a", tuple(v.reshape(-1).tolist()))
+			if isinstance(v, dict):
+				return tuple(sorted((str(k), freeze(x)) for k, x in v.items()))
+			if isinstance(v, (list, tuple)):
+				return tuple(freeze(x) for x in v)
+			return v
+		return (freeze(self.s), id(kernel), freeze(kernel.params_dict), tuple(kernel.operations))
 
 	# ------------------------------------------------------------------ lazily materialised reference attributes
 	@property
@@ -277,17 +297,24 @@ class GaussianProcess:
 		sqrt(alpha^T y - s^2 alpha^T alpha): no n x n matrix is formed."""
 		if not self.fitted:
 			return None
-		a = self._alpha.reshape(-1)
+		lib = _lib.load()
+		a = self._alpha.reshape(-1).contiguous()
+
+		def dot(u, v):          # <u, v> as a 1 x 1 NT product (the bandwidth-bound row kernel of stpy_gemm_nt)
+			o = torch.empty((1, 1), dtype=u.dtype, device=u.device)
+			_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(u.dtype), 1, 1, u.shape[0], _lib.ptr(u), u.shape[0], _lib.ptr(v), v.shape[0],
+										_lib.ptr(o), 1, 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
+			return o.reshape(())
 		if self._Sigma is None:
-			noise = float(self.s) ** 2 * torch.dot(a, a)
+			noise = float(self.s) ** 2 * dot(a, a)
 		else:                                   # general noise matrix: alpha^T Sigma^T Sigma alpha = |Sigma alpha|^2
-			lib = _lib.load()
 			Sd = _lib.to_device(self._Sigma, a.dtype).contiguous()
 			v = torch.empty((1, Sd.shape[0]), dtype=a.dtype, device=a.device)
 			_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(a.dtype), 1, Sd.shape[0], Sd.shape[1], _lib.ptr(a), a.shape[0], _lib.ptr(Sd), Sd.stride(0),
 										_lib.ptr(v), v.stride(0), 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
-			noise = torch.dot(v.reshape(-1), v.reshape(-1))
-		val = torch.dot(a, self._yd.reshape(-1)) - noise
+			v = v.reshape(-1)
+			noise = dot(v, v)
+		val = dot(a, self._yd.reshape(-1).contiguous()) - noise
 		return _lib.like_input(torch.sqrt(val).reshape(1, 1), self.x)
 
 	def beta(self, delta=1e-3, norm=1):
@@ -356,8 +383,8 @@ class GaussianProcess:
 		if mp > m:
 			X[m:, :].zero_()
 		tw = torch.empty((int(lib.stpy_trsm_workspace_bytes(dt, mp, n, self.nb)),), dtype=torch.uint8, device=X.device)
-		_lib.check(lib.stpy_trsm_right_lt(dt, mp, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv),
-										  _lib.ptr(X), X.stride(0), self.nb, _lib.ptr(tw), tw.numel() * tw.element_size(), st()), "stpy_trsm_right_lt")   # X = K* L^-T
+		_lib.check(lib.stpy_trsm_right_lt(dt, mp, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv), self._winv.numel(),
+										  _lib.ptr(X), X.stride(0), self.nb, 0, _lib.ptr(tw), tw.numel() * tw.element_size(), st()), "stpy_trsm_right_lt")   # X = K* L^-T
 		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
 		if not full:
 			kd = torch.empty((m,), dtype=xd.dtype, device=xd.device)
@@ -411,7 +438,7 @@ class GaussianProcess:
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(nn)),), dtype=C.dtype, device=C.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, nn, self.nb)),), dtype=torch.uint8, device=C.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=C.device)
-		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), C.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
+		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), C.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
 		bad = int(info.item())
 		if bad != 0:
 			raise torch.linalg.LinAlgError("sample: posterior covariance + jitter is not positive definite (leading minor %d)" % bad)
@@ -471,7 +498,8 @@ class GaussianProcess:
 			self._xd = _lib.to_device(self.x)
 			self._yd = _lib.to_device(self.y, self._xd.dtype).reshape(-1, 1)
 			self.n = self._xd.shape[0]
-		reuse = self.fitted and (not X) and (kernel is self.kernel_object) and self._Sigma is None
+		reuse = (self.fitted and (not X) and (kernel is self.kernel_object) and self._Sigma is None
+				 and getattr(self, "_factor_key", None) == self._hyper_key(kernel))
 		if reuse:
 			L, winv, z = self._L, self._winv, self._z
 		else:
@@ -515,7 +543,7 @@ class GaussianProcess:
 		alpha = self._backward_z(L, winv, z)[:n]
 		Kinv_p = torch.empty((npad, npad), dtype=L.dtype, device=L.device)
 		work_p = torch.empty((npad, npad), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_potri(dt, npad, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(Kinv_p), Kinv_p.stride(0), _lib.ptr(work_p), work_p.numel() * work_p.element_size(), st()), "stpy_potri")
+		_lib.check(lib.stpy_potri(dt, npad, _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(Kinv_p), Kinv_p.stride(0), _lib.ptr(work_p), work_p.numel() * work_p.element_size(), st()), "stpy_potri")
 		# inverse of the bordered matrix = [[K^-1, 0], [0, I]]: everything below works on the leading n x n views
 		Kinv, work = Kinv_p[:n, :n], work_p[:n, :n]
 		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), Kinv.stride(0), st()), "stpy_symmetrize_lower")
@@ -538,15 +566,13 @@ class GaussianProcess:
 				identity = (group == list(range(xd.shape[1])))
 				cols = None if identity else _dev_const(group, None, xd.device, int32=True)
 				inv_ls = _dev_const(term['inv_ls'], xd.dtype, xd.device)
-				# H <- (w K^-1 - alpha alpha^T) o kappa F_t, in `work` unless this is the only term (then in place)
-				if single:
-					H = Kinv
-				else:
-					H = work
-					H.copy_(Kinv)
+				# H <- (w K^-1 - alpha alpha^T) o kappa F_t: in place over K^-1 when this is the only term, otherwise written
+				# to `work` with K^-1 only read (no N x N copy)
+				H = Kinv if single else work
 				ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
 				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(xd), n, xd.stride(0), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
-											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(H), H.stride(0), _lib.ptr(ws), ws.numel() * ws.element_size(), st()), "stpy_lml_weight")
+											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(H), H.stride(0),
+											   _lib.ptr(ws), ws.numel() * ws.element_size(), st()), "stpy_lml_weight")
 				# ... o M_i
 				factors = []
 				if it['op'] == "*" and i > 0:
@@ -555,10 +581,14 @@ class GaussianProcess:
 					if items[j]['op'] == "*":
 						factors.append([items[j]])
 				for fac in factors:
+					if len(fac) == 1 and len(fac[0]['terms']) == 1:
+						# a single-term factor multiplies straight into H (STPY_OUT_MUL combine of stpy_gram)
+						kernel._run_items([dict(fac[0], op="*")], xd, xd, H, first_is_set=False)
+						continue
 					if tmp is None:
 						tmp = torch.empty((n, n), dtype=L.dtype, device=L.device)
 					kernel._run_items(fac, xd, xd, tmp)
-					H.mul_(tmp)
+					_lib.check(lib.stpy_combine(dt, n, n, _lib.ptr(H), H.stride(0), _lib.ptr(tmp), tmp.stride(0), _lib.OUT_MUL, 0.0, st()), "stpy_combine")
 				xs = (xd if identity else xd[:, group]) * inv_ls                              # scaled coordinates (n, dg)
 				dg = xs.shape[1]
 				XT = torch.cat([xs.T, torch.ones((1, n), dtype=xs.dtype, device=xs.device)]).contiguous()      # (dg + 1, n): NT operand

@@ -126,7 +126,7 @@ class KernelizedFeatures:
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(m)),), dtype=V.dtype, device=V.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, m, self.nb)),), dtype=torch.uint8, device=V.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=V.device)
-		_lib.check(lib.stpy_potrf(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb, _lib.ptr(info), st()), "stpy_potrf")
+		_lib.check(lib.stpy_potrf(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), st()), "stpy_potrf")
 		bad = int(info.item())
 		if bad != 0:
 			raise torch.linalg.LinAlgError("KernelizedFeatures: Phi^T Phi + s^2 lam I is not positive definite (leading minor %d)" % bad)
@@ -134,10 +134,10 @@ class KernelizedFeatures:
 		rhs = torch.empty((m,), dtype=V.dtype, device=V.device)
 		_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(yd), None, _lib.ptr(rhs), None, 0, st()), "stpy_predict")
 		u = torch.empty_like(rhs)
-		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), _lib.ptr(rhs), _lib.ptr(u), 0, st()), "stpy_trsv")
+		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(rhs), _lib.ptr(u), 0, st()), "stpy_trsv")
 		scratch = u.clone()
 		theta = torch.empty_like(u)
-		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), _lib.ptr(scratch), _lib.ptr(theta), 1, st()), "stpy_trsv")
+		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(theta), 1, st()), "stpy_trsv")
 		self._L, self._winv, self._u, self._theta = V, winv, u, theta
 		self.fitted = True
 		return None
@@ -163,7 +163,7 @@ class KernelizedFeatures:
 		dt = _lib.dtype_code(L.dtype)
 		out = torch.empty((m, m), dtype=L.dtype, device=L.device)
 		work = torch.empty((m, m), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_potri(dt, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), _lib.ptr(out), out.stride(0), _lib.ptr(work), work.numel() * work.element_size(), _lib.stream_ptr()), "stpy_potri")
+		_lib.check(lib.stpy_potri(dt, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), self._winv.numel(), _lib.ptr(out), out.stride(0), _lib.ptr(work), work.numel() * work.element_size(), _lib.stream_ptr()), "stpy_potri")
 		_lib.check(lib.stpy_symmetrize_lower(dt, m, _lib.ptr(out), out.stride(0), _lib.stream_ptr()), "stpy_symmetrize_lower")
 		return _lib.like_input(out, self.x)
 
@@ -195,7 +195,7 @@ class KernelizedFeatures:
 		M, m = X.shape
 		dt = _lib.dtype_code(L.dtype)
 		st = _lib.stream_ptr
-		_lib.check(lib.stpy_trsm_right_lt(dt, M, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), _lib.ptr(X), X.stride(0), self.nb, None, 0, st()), "stpy_trsm_right_lt")
+		_lib.check(lib.stpy_trsm_right_lt(dt, M, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), self._winv.numel(), _lib.ptr(X), X.stride(0), self.nb, 0, None, 0, st()), "stpy_trsm_right_lt")
 		mu, ss = torch.empty((M,), dtype=L.dtype, device=L.device), torch.empty((M,), dtype=L.dtype, device=L.device)
 		_lib.check(lib.stpy_predict(dt, M, m, _lib.ptr(X), X.stride(0), _lib.ptr(self._u), None, _lib.ptr(mu), _lib.ptr(ss), 2, st()), "stpy_predict")
 		std = float(self.s) * torch.sqrt(ss)

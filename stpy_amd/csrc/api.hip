@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -30,28 +32,42 @@ int check_launch(const char* what)
 }
 
 // ---- launch profiler -------------------------------------------------------------------------
+// (the record table is shared by every host thread that launches while the profiler is on: slots are handed out and
+// read under a mutex; the events themselves are recorded on the launching thread's stream)
 struct ProfRec { hipEvent_t e0, e1; double flops; int tag; };
+static std::mutex g_prof_mutex;
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 
 ProfScope::ProfScope(int tag, double flops, hipStream_t st_) : slot(-1), st(st_)
 {
-	if (!g_prof_on) return;
-	if (g_prof_used == g_prof.size()) {
-		ProfRec r;
-		if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-		g_prof.push_back(r);
+	if (!g_prof_on.load(std::memory_order_relaxed)) return;
+	hipEvent_t e0;
+	{
+		std::lock_guard<std::mutex> lock(g_prof_mutex);
+		if (g_prof_used == g_prof.size()) {
+			ProfRec r;
+			if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+			g_prof.push_back(r);
+		}
+		slot = (int)g_prof_used++;
+		g_prof[slot].flops = flops;
+		g_prof[slot].tag = tag;
+		e0 = g_prof[slot].e0;
 	}
-	slot = (int)g_prof_used++;
-	g_prof[slot].flops = flops;
-	g_prof[slot].tag = tag;
-	(void)hipEventRecord(g_prof[slot].e0, st);
+	(void)hipEventRecord(e0, st);
 }
 
 ProfScope::~ProfScope()
 {
-	if (slot >= 0) (void)hipEventRecord(g_prof[slot].e1, st);
+	if (slot < 0) return;
+	hipEvent_t e1;
+	{
+		std::lock_guard<std::mutex> lock(g_prof_mutex);
+		e1 = g_prof[slot].e1;
+	}
+	(void)hipEventRecord(e1, st);
 }
 
 }  // namespace stpy
@@ -72,6 +88,8 @@ const char* stpy_version(void) { return "stpy_hip 0.1 (gfx950)"; }
 const char* stpy_last_error_string(void) { return g_err; }
 
 // a workspace that is too small is refused here: the kernels cannot check it and would write past its end
+#define WINV_CHECK(fn, have, n_) do { const int64_t need_ = stpy_potrf_winv_elems(n_); if ((have) < need_) { \
+	set_error(fn ": winv holds %lld elements, %lld needed (stpy_potrf_winv_elems(n))", (long long)(have), (long long)need_); return -21; } } while (0)
 #define WORK_CHECK(fn, have, need) do { const int64_t need_ = (need); if ((have) < need_) { \
 	set_error(fn ": workspace of %lld bytes, %lld needed (see the *_workspace_bytes query for these arguments)", (long long)(have), (long long)need_); return -20; } } while (0)
 
@@ -82,7 +100,10 @@ int stpy_gram(int kind, int dtype, const void* a, int64_t n, int64_t lda, const 
 	if (n <= 0 || q <= 0) return 0;          // empty problem: nothing to write (empty tensors have null data pointers)
 	if (!a || !b || !out || !inv_ls) { set_error("stpy_gram: null pointer"); return -3; }
 	if (work) WORK_CHECK("stpy_gram", work_bytes, stpy_gram_workspace_bytes(dtype, n, q, d));
-	if (d <= 0 || lda < 1 || ldb < 1 || ldo < n) { set_error("stpy_gram: bad dimensions d=%d ldo=%lld n=%lld", d, (long long)ldo, (long long)n); return -9; }
+	if (d <= 0 || ldo < n) { set_error("stpy_gram: bad dimensions d=%d ldo=%lld n=%lld", d, (long long)ldo, (long long)n); return -9; }
+	// (with a column subset the rows must hold the largest selected column, which lives on the device: the caller's
+	// contract; without one the first d columns are read)
+	if (lda < 1 || ldb < 1 || (!cols && (lda < d || ldb < d))) { set_error("stpy_gram: leading dimensions lda=%lld ldb=%lld below d=%d", (long long)lda, (long long)ldb, d); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         gram<double>(kind, (const double*)a, n, lda, (const double*)b, q, ldb, d, cols, (const double*)inv_ls, kappa, offset, diag_add, lower_only, combine, (double*)out, ldo, work, st),
@@ -99,7 +120,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, i
 {
 	if (m <= 0) return 0;
 	if (!x || !out || !inv_ls) { set_error("stpy_gram_diag: null pointer"); return -3; }
-	if (d < 0 || ldx < 1) { set_error("stpy_gram_diag: bad dimensions"); return -5; }
+	if (d < 0 || ldx < 1 || (!cols && ldx < d)) { set_error("stpy_gram_diag: bad dimensions"); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         gram_diag<double>(kind, (const double*)x, m, ldx, d, cols, (const double*)inv_ls, kappa, offset, combine, (double*)out, st),
@@ -114,15 +135,19 @@ int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
 
 int64_t stpy_potrf_winv_elems(int64_t n) { return ((n + IB - 1) / IB) * (int64_t)IB * IB; }
 
-int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, void* work, int64_t work_bytes, int nb, int32_t* info_dev, void* stream)
+int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, int64_t winv_elems, void* work, int64_t work_bytes, int nb, int flags,
+               int32_t* info_dev, void* stream)
 {
 	if (!A || !winv || !work || !info_dev) { set_error("stpy_potrf: null pointer"); return -3; }
 	if (n <= 0 || lda < n) { set_error("stpy_potrf: bad dimensions n=%lld lda=%lld", (long long)n, (long long)lda); return -2; }
+	WINV_CHECK("stpy_potrf", winv_elems, n);
 	WORK_CHECK("stpy_potrf", work_bytes, stpy_potrf_workspace_bytes(dtype, n, nb));
+	if (flags & ~STPY_FLAG_BESIDE_UPDATE) { set_error("stpy_potrf: unknown flag bits 0x%x", flags); return -10; }
 	hipStream_t st = (hipStream_t)stream;
+	const int gf = (flags & STPY_FLAG_BESIDE_UPDATE) ? GEMM_NO_K128 : 0;
 	DISPATCH(dtype,
-	         potrf<double>(n, (double*)A, lda, (double*)winv, (double*)work, nb, info_dev, st),
-	         potrf<float>(n, (float*)A, lda, (float*)winv, (float*)work, nb, info_dev, st));
+	         potrf<double>(n, (double*)A, lda, (double*)winv, (double*)work, nb, info_dev, st, gf),
+	         potrf<float>(n, (float*)A, lda, (float*)winv, (float*)work, nb, info_dev, st, gf));
 }
 
 int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
@@ -134,22 +159,27 @@ int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
 	return (int64_t)TRSM_MAX_PASSES * m * nb * (int64_t)(dtype == STPY_F32 ? 4 : 8);
 }
 
-int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, void* B, int64_t ldb, int nb, void* work, int64_t work_bytes, void* stream)
+int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t ldl, const void* winv, int64_t winv_elems, void* B, int64_t ldb, int nb, int flags,
+                       void* work, int64_t work_bytes, void* stream)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (!L || !winv || !B) { set_error("stpy_trsm_right_lt: null pointer"); return -4; }
+	WINV_CHECK("stpy_trsm_right_lt", winv_elems, n);
+	if (flags & ~STPY_FLAG_BESIDE_UPDATE) { set_error("stpy_trsm_right_lt: unknown flag bits 0x%x", flags); return -11; }
+	const int gf = (flags & STPY_FLAG_BESIDE_UPDATE) ? GEMM_NO_K128 : 0;
 	if (work) WORK_CHECK("stpy_trsm_right_lt", work_bytes, stpy_trsm_workspace_bytes(dtype, m, n, nb));
 	if (m < 0 || n <= 0 || ldl < n || ldb < n) { set_error("stpy_trsm_right_lt: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         trsm_right_lt<double>(m, n, (const double*)L, ldl, (const double*)winv, (double*)B, ldb, nb, st, false, (double*)work),
-	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st, false, (float*)work));
+	         trsm_right_lt<double>(m, n, (const double*)L, ldl, (const double*)winv, (double*)B, ldb, nb, st, false, (double*)work, gf),
+	         trsm_right_lt<float>(m, n, (const float*)L, ldl, (const float*)winv, (float*)B, ldb, nb, st, false, (float*)work, gf));
 }
 
-int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* Kinv, int64_t ldk, void* work, int64_t work_bytes, void* stream)
+int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, int64_t winv_elems, void* Kinv, int64_t ldk, void* work, int64_t work_bytes, void* stream)
 {
 	if (!L || !winv || !Kinv || !work) { set_error("stpy_potri: null pointer"); return -3; }
 	if (n <= 0 || ldl < n || ldk < n) { set_error("stpy_potri: bad dimensions"); return -2; }
+	WINV_CHECK("stpy_potri", winv_elems, n);
 	WORK_CHECK("stpy_potri", work_bytes, n * n * (int64_t)(dtype == STPY_F32 ? 4 : 8));
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
@@ -158,20 +188,24 @@ int stpy_potri(int dtype, int64_t n, const void* L, int64_t ldl, const void* win
 }
 
 int stpy_lml_weight(int kind, int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
-                    double kappa, double weight, const void* alpha, void* H, int64_t ldh, void* work, int64_t work_bytes, void* stream)
+                    double kappa, double weight, const void* alpha, const void* Kinv, int64_t ldk, void* H, int64_t ldh, void* work, int64_t work_bytes, void* stream)
 {
 	if (!x || !inv_ls || !alpha || !H || !work) { set_error("stpy_lml_weight: null pointer"); return -3; }
+	if (Kinv == H) Kinv = nullptr;          // in place
+	if (Kinv && ldk < n) { set_error("stpy_lml_weight: ldk=%lld < n=%lld", (long long)ldk, (long long)n); return -13; }
+	if (n <= 0 || d <= 0 || ldh < n || ldx < 1 || (!cols && ldx < d)) { set_error("stpy_lml_weight: bad dimensions n=%lld d=%d ldx=%lld ldh=%lld", (long long)n, d, (long long)ldx, (long long)ldh); return -5; }
 	WORK_CHECK("stpy_lml_weight", work_bytes, stpy_gram_workspace_bytes(dtype, n, n, d));
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         lml_weight<double>(kind, (const double*)x, n, ldx, d, cols, (const double*)inv_ls, kappa, weight, (const double*)alpha, (double*)H, ldh, work, st),
-	         lml_weight<float>(kind, (const float*)x, n, ldx, d, cols, (const float*)inv_ls, kappa, weight, (const float*)alpha, (float*)H, ldh, work, st));
+	         lml_weight<double>(kind, (const double*)x, n, ldx, d, cols, (const double*)inv_ls, kappa, weight, (const double*)alpha, (const double*)Kinv, ldk, (double*)H, ldh, work, st),
+	         lml_weight<float>(kind, (const float*)x, n, ldx, d, cols, (const float*)inv_ls, kappa, weight, (const float*)alpha, (const float*)Kinv, ldk, (float*)H, ldh, work, st));
 }
 
-int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, void* y, void* out, int trans, void* stream)
+int stpy_trsv(int dtype, int64_t n, const void* L, int64_t ldl, const void* winv, int64_t winv_elems, void* y, void* out, int trans, void* stream)
 {
 	if (!L || !winv || !y || !out || y == out) { set_error("stpy_trsv: null or aliased pointer (y is scratch, out must differ)"); return -3; }
 	if (n <= 0 || ldl < n) { set_error("stpy_trsv: bad dimensions"); return -2; }
+	WINV_CHECK("stpy_trsv", winv_elems, n);
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
 	         trsv<double>(n, (const double*)L, ldl, (const double*)winv, (double*)y, (double*)out, trans, st),
@@ -188,6 +222,28 @@ int stpy_predict(int dtype, int64_t m, int64_t n, const void* X, int64_t ldx, co
 	DISPATCH(dtype,
 	         predict<double>(m, n, (const double*)X, ldx, (const double*)z, (const double*)kdiag, (double*)mu, (double*)sigma, clamp, st),
 	         predict<float>(m, n, (const float*)X, ldx, (const float*)z, (const float*)kdiag, (float*)mu, (float*)sigma, clamp, st));
+}
+
+int stpy_predict_finish(int dtype, int64_t m, void* mu, const void* sumsq, const void* kdiag, double scale, void* sigma, int clamp, void* stream)
+{
+	if (m <= 0) return 0;
+	if (sigma && (!sumsq || !kdiag)) { set_error("stpy_predict_finish: sigma needs sumsq and kdiag"); return -4; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         predict_finish<double>(m, (double*)mu, (const double*)sumsq, (const double*)kdiag, scale, (double*)sigma, clamp, st),
+	         predict_finish<float>(m, (float*)mu, (const float*)sumsq, (const float*)kdiag, scale, (float*)sigma, clamp, st));
+}
+
+int stpy_combine(int dtype, int64_t m, int64_t n, void* out, int64_t ldo, const void* src, int64_t lds, int combine, double diag_add, void* stream)
+{
+	if (m <= 0 || n <= 0) return 0;
+	if (!out || !src) { set_error("stpy_combine: null pointer"); return -4; }
+	if (ldo < n || lds < n) { set_error("stpy_combine: leading dimensions ldo=%lld lds=%lld below n=%lld", (long long)ldo, (long long)lds, (long long)n); return -5; }
+	if (combine < STPY_OUT_SET || combine > STPY_OUT_MUL) { set_error("stpy_combine: unknown combine %d", combine); return -8; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         combine_into<double>(m, n, (double*)out, ldo, (const double*)src, lds, combine, diag_add, st),
+	         combine_into<float>(m, n, (float*)out, ldo, (const float*)src, lds, combine, diag_add, st));
 }
 
 int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const void* z, void* out2, void* stream)
@@ -245,7 +301,7 @@ int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k, const void* A, i
 	BlockCyclic bc{nb_dist, pr, pc, myr, myc, i0, j0};
 	// algorithmic flops: only the distribution blocks on or below the global diagonal are computed
 	double elems = (double)m * (double)n;
-	if (g_prof_on && nb_dist >= 128 && nb_dist % 128 == 0) {
+	if (g_prof_on.load() && nb_dist >= 128 && nb_dist % 128 == 0) {
 		elems = 0;
 		for (int64_t bi = 0; bi * nb_dist < m; ++bi) {
 			const int64_t I = (bi + i0) * pr + myr, rows = std::min<int64_t>(nb_dist, m - bi * nb_dist);
@@ -268,15 +324,15 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
 }
 
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, const void* W, int64_t ldw, int64_t m,
-                   const void* bias, double scale, void* out, int64_t ldo, int transposed, void* stream)
+                   const void* bias, const void* feat_scale, double scale, void* out, int64_t ldo, int transposed, void* stream)
 {
 	if (n <= 0 || m <= 0) return 0;
 	if (!x || !W || !out) { set_error("stpy_rff_embed: null pointer"); return -2; }
 	if (d <= 0 || ldx < d || ldw < d || ldo < (transposed ? n : m)) { set_error("stpy_rff_embed: bad dimensions"); return -5; }
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, scale, (double*)out, ldo, transposed, st),
-	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, scale, (float*)out, ldo, transposed, st));
+	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, (const double*)feat_scale, scale, (double*)out, ldo, transposed, st),
+	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, (const float*)feat_scale, scale, (float*)out, ldo, transposed, st));
 }
 
 /* experiment knobs (benchmarks only): key 0 = gemm first-round stagger on/off */
@@ -314,14 +370,16 @@ int stpy_tune_get(int key)
 
 void stpy_profile_enable(int enable)
 {
-	g_prof_on = enable != 0;
-	if (g_prof_on) g_prof_used = 0;
+	std::lock_guard<std::mutex> lock(g_prof_mutex);
+	if (enable) g_prof_used = 0;
+	g_prof_on.store(enable != 0);
 }
 
 int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* launches)
 {
 	double ms = 0, fl = 0;
 	int64_t cnt = 0;
+	std::lock_guard<std::mutex> lock(g_prof_mutex);
 	for (size_t i = 0; i < g_prof_used; ++i) {
 		if (g_prof[i].tag != tag) continue;
 		if (hipEventSynchronize(g_prof[i].e1) != hipSuccess) { set_error("stpy_profile_read: event sync failed"); return -1; }
@@ -344,6 +402,7 @@ int stpy_profile_read_union(int tagmask, double* busy_ms, double* total_flops, i
 	double fl = 0;
 	int64_t cnt = 0;
 	hipEvent_t base = nullptr;
+	std::lock_guard<std::mutex> lock(g_prof_mutex);
 	for (size_t i = 0; i < g_prof_used; ++i) {
 		if (!((tagmask >> g_prof[i].tag) & 1)) continue;
 		if (hipEventSynchronize(g_prof[i].e1) != hipSuccess) { set_error("stpy_profile_read_union: event sync failed"); return -1; }

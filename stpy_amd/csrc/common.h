@@ -22,15 +22,17 @@ extern int g_potf2_scalar;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
-// ---- look-ahead side stream (highest priority) + events shared by potrf and the block solves; one set per
-// ---- process, created on first use
+// ---- look-ahead side stream (highest priority) + events used by potrf and the block solves.  One set per
+// ---- (device, caller stream), created on first use and kept for the life of the process: two host threads that
+// ---- drive two streams never share a side stream or an event, and calls on ONE stream are ordered by that stream.
 struct LookAhead {
 	hipStream_t side = nullptr;
 	hipEvent_t col_ready = nullptr, panel_done = nullptr, trail_done = nullptr;
-	int device = -1;
 };
-int lookahead_init();
-LookAhead* lookahead_state();
+int lookahead_acquire(hipStream_t caller, LookAhead** out);
+
+// per-call behaviour flags of stpy_potrf / stpy_trsm_right_lt (include/stpy_hip.h: STPY_FLAG_*), passed down to the GEMM launcher
+constexpr int GEMM_NO_K128 = 1;      // = STPY_FLAG_BESIDE_UPDATE: never take the 128 KiB one-volley kernel
 
 // ---- optional launch profiler (stpy_profile_*): HIP events recorded on the launch stream around
 // ---- every tagged kernel, so bench.py can report the dominant kernel's live average duration.
@@ -75,19 +77,19 @@ template <> struct Mfma<float> {
 
 // ---- internal launchers (all enqueue on `st`, return 0 or a negative error code) ----
 struct BlockCyclic { int nb_dist, pr, pc, myr, myc, i0, j0; };
-template <typename T> struct RffEpilogue { int half; T scale; const T* bias; int by_row; };
+template <typename T> struct RffEpilogue { int half; T scale; const T* bias; int by_row; const T* fscale; };
 template <typename T> struct GramEpilogue { int kind, combine; T kappa, offset, diag_add; const T* na; const T* nb; const T* alpha; T weight; };
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
-            const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr, int ksplit = 1, T* split_work = nullptr);
+            const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr, int ksplit = 1, T* split_work = nullptr, int gflags = 0);
 int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);      // recommended number of K passes for a product with few output tiles
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st);
 template <typename T>
-int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st);
+int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st, int gflags = 0);
 template <typename T>
-int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false, T* work = nullptr);
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false, T* work = nullptr, int gflags = 0);
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
 extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking;
@@ -96,7 +98,11 @@ template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
 template <typename T>
 int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, double kappa, double weight,
-               const T* alpha, T* H, int64_t ldh, void* work, hipStream_t st);
+               const T* alpha, const T* Hsrc, int64_t ldhs, T* H, int64_t ldh, void* work, hipStream_t st);
+template <typename T>
+int combine_into(int64_t m, int64_t n, T* out, int64_t ldo, const T* src, int64_t lds, int combine, double diag_add, hipStream_t st);
+template <typename T>
+int predict_finish(int64_t m, T* mu, const T* sumsq, const T* kdiag, double scale, T* sigma, int clamp, hipStream_t st);
 template <typename T>
 int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int trans, hipStream_t st);
 template <typename T>
@@ -115,6 +121,6 @@ int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t
               double kappa, double offset, int combine, T* out, hipStream_t st);
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
-              const T* bias, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
+              const T* bias, const T* feat_scale, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
 
 }  // namespace stpy

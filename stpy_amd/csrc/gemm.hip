@@ -52,6 +52,7 @@ struct GemmArgs {
 	int epi_half;            // mode 2: columns < epi_half take cos, the rest sin (all cos when epi_bias != null)
 	T epi_scale;             // mode 2: output scale sqrt(2/m) sqrt(kappa)
 	const T* epi_bias;       // mode 2: optional phase per column
+	const T* epi_fscale;     // mode 2: optional amplitude per feature (quadrature weights), multiplies epi_scale
 	int epi_by_row;          // mode 2: features run along the ROWS of C (transposed embedding Phi^T)
 	// mode 3: Gram epilogue  C[j][i] (op)= kappa * phi(nb[j] + na[i] - 2 acc) (+ offset) + diag_add [i == j]
 	const T* g_na; const T* g_nb;
@@ -362,12 +363,13 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// kernel, 5x slower (guide rule 20).  fp64 embeds take the unfused route in rff.hip instead.
 	if constexpr (EPI == 2) {
 		if (!p.epi_by_row) {
-			T bias[4];
+			T bias[4], fsc[4];
 			bool use_cos[4];
 #pragma unroll
 			for (int tn = 0; tn < 4; ++tn) {
 				const int col = col0 + wn * 64 + r16 + tn * 16;
 				bias[tn] = p.epi_bias ? p.epi_bias[GUARD ? min(col, p.n - 1) : col] : T(0);
+				fsc[tn] = p.epi_scale * (p.epi_fscale ? p.epi_fscale[GUARD ? min(col, p.n - 1) : col] : T(1));
 				use_cos[tn] = p.epi_bias != nullptr || col < p.epi_half;
 			}
 #pragma unroll
@@ -376,7 +378,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 				for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
 					for (int i = 0; i < 4; ++i)
-						acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + bias[tn], use_cos[tn], p.epi_scale);
+						acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + bias[tn], use_cos[tn], fsc[tn]);
 		} else {
 #pragma unroll
 			for (int tm = 0; tm < 4; ++tm)
@@ -384,9 +386,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 				for (int i = 0; i < 4; ++i) {
 					const int row = row0 + wm * 64 + tm * 16 + MM::crow(lane, i);
 					const T b = p.epi_bias ? p.epi_bias[GUARD ? min(row, p.m - 1) : row] : T(0);
+					const T fs = p.epi_scale * (p.epi_fscale ? p.epi_fscale[GUARD ? min(row, p.m - 1) : row] : T(1));
 					const bool uc = p.epi_bias != nullptr || row < p.epi_half;
 #pragma unroll
-					for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + b, uc, p.epi_scale);
+					for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = rff_value<T>(acc[tm][tn][i] + b, uc, fs);
 				}
 		}
 	}
@@ -460,9 +463,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		}
 	}
 
-	// ---- evidence-gradient weight (mode 4): H = (w K^-1 - alpha alpha^T) o F, in place over K^-1
+	// ---- evidence-gradient weight (mode 4): H = (w K^-1 - alpha alpha^T) o F, in place over K^-1 (or K^-1 read from C2)
 	if constexpr (EPI == 4) {
 		T* const ns = smem;
+		const T* const stile = p.C2 ? p.C2 + (int64_t)row0 * p.ldc2 + col0 : ctile;
+		const unsigned lds32 = p.C2 ? (unsigned)p.ldc2 : ldc32;
 		if (tid < BN) { const int col = col0 + tid; ns[tid] = p.g_na[GUARD ? min(col, p.n - 1) : col]; ns[2 * BN + tid] = p.g_alpha[GUARD ? min(col, p.n - 1) : col]; }
 		else { const int row = row0 + tid - BN; ns[tid] = p.g_nb[GUARD ? min(row, p.m - 1) : row]; ns[2 * BN + tid] = p.g_alpha[GUARD ? min(row, p.m - 1) : row]; }
 		__syncthreads();
@@ -497,7 +502,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 				for (int tn = 0; tn < 4; ++tn) {
 					const int lc = wn * 64 + r16 + tn * 16;
-					old[tn][i] = ctile[(unsigned)lrc * ldc32 + (unsigned)(GUARD ? min(lc, p.n - 1 - col0) : lc)];
+					old[tn][i] = stile[(unsigned)lrc * lds32 + (unsigned)(GUARD ? min(lc, p.n - 1 - col0) : lc)];
 				}
 			}
 #pragma unroll
@@ -529,7 +534,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 				else crow[tn * 16] = acc[tm][tn][i];
 			}
 		}
-	if (p.C2) {         // second copy (panel workspace of potrf): one uniform branch around all its stores
+	if (EPI != 4 && p.C2) {         // second copy (panel workspace of potrf): one uniform branch around all its stores
 		T* const c2tile = p.C2 + (int64_t)row0 * p.ldc2 + col0;
 #pragma unroll
 		for (int tm = 0; tm < 4; ++tm)
@@ -937,7 +942,7 @@ static int gemm_skinny(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda,
 template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc, const RffEpilogue<T>* rff,
-            const GramEpilogue<T>* gr, int ksplit, T* split_work)
+            const GramEpilogue<T>* gr, int ksplit, T* split_work, int gflags)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (k <= 0) {
@@ -963,10 +968,10 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.tiles_m = (int)((m + BM - 1) / BM);
 	p.tiles_n = (int)((n + BN - 1) / BN);
 	p.mode = mode;
-	p.epi_half = 0; p.epi_scale = T(1); p.epi_bias = nullptr; p.epi_by_row = 0;
+	p.epi_half = 0; p.epi_scale = T(1); p.epi_bias = nullptr; p.epi_fscale = nullptr; p.epi_by_row = 0;
 	if (mode == 2) {
 		if (!rff || sizeof(T) != 4) { set_error("gemm_nt: mode 2 (fused RFF epilogue) is fp32 only and needs its parameters"); return -12; }
-		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias; p.epi_by_row = rff->by_row;
+		p.epi_half = rff->half; p.epi_scale = rff->scale; p.epi_bias = rff->bias; p.epi_fscale = rff->fscale; p.epi_by_row = rff->by_row;
 	}
 	p.g_na = p.g_nb = nullptr; p.g_kappa = T(1); p.g_offset = p.g_diag = T(0); p.g_kind = 0; p.g_combine = 0;
 	p.g_alpha = nullptr; p.g_w = T(1); p.kskip = 0;
@@ -1024,7 +1029,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	if constexpr (sizeof(T) == 8) {
 		// the panel chain's K = 128 products (see gemm_nt_k128_kernel)
 		const int64_t t64 = ((m + 63) / 64) * (n / 64);
-		if (g_gemm_k128 && k == 128 && (n % 128 == 0) && (mode == 0 || mode == 1) && !lower_only && !bc && p.ksplit == 1 && !g_gemm_exp &&
+		if (g_gemm_k128 && !(gflags & GEMM_NO_K128) && k == 128 && (n % 128 == 0) && (mode == 0 || mode == 1) && !lower_only && !bc && p.ksplit == 1 && !g_gemm_exp &&
 		    t64 <= g_gemm_k128 && (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {
 			const dim3 g64((unsigned)((m + 63) / 64), (unsigned)(n / 128));
 			if (mode == 1) hipLaunchKernelGGL((gemm_nt_k128_kernel<true>), g64, block, 0, st, p);
@@ -1063,8 +1068,8 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	return check_launch("gemm_nt");
 }
 
-template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*, const GramEpilogue<double>*, int, double*);
-template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*, const GramEpilogue<float>*, int, float*);
+template int gemm_nt<double>(int64_t, int64_t, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, double*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<double>*, const GramEpilogue<double>*, int, double*, int);
+template int gemm_nt<float>(int64_t, int64_t, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int, int, hipStream_t, const BlockCyclic*, const RffEpilogue<float>*, const GramEpilogue<float>*, int, float*, int);
 
 int gemm_splitk_plan(int64_t m, int64_t n, int64_t k)
 {

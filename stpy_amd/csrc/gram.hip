@@ -232,11 +232,60 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 	return check_launch("gram");
 }
 
-// H = (weight * Kinv - alpha alpha^T) o F  in place over the symmetric Kinv (n x n), F the derivative
-// factor of the kernel family (see gemm.hip, mode 4).  Same workspace layout as gram().
+// out (op)= src elementwise over an m x n window (+ diag_add on the diagonal afterwards): the kernel algebra's fold of a
+// multi-term item (kernels.py:146-157) and the M_i factors of the evidence gradient.  HBM-bound: one 16-byte access per
+// lane where alignment allows.
+template <typename T>
+__global__ __launch_bounds__(256)
+void combine_kernel(T* __restrict__ out, int64_t ldo, const T* __restrict__ src, int64_t lds, int64_t row0, int64_t n, int combine, T diag_add, int vec)
+{
+	constexpr int CH = 16 / (int)sizeof(T);
+	typedef T vch __attribute__((ext_vector_type(CH)));
+	const int64_t row = row0 + blockIdx.y;
+	T* o = out + row * ldo;
+	const T* s = src + row * lds;
+	if (vec) {
+		const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CH;
+		if (c0 >= n) return;
+		vch a = *(const vch*)(o + c0);
+		const vch b = *(const vch*)(s + c0);
+		a = combine == STPY_OUT_ADD ? a + b : (combine == STPY_OUT_MUL ? a * b : b);
+#pragma unroll
+		for (int e = 0; e < CH; ++e) if (c0 + e == row) a[e] += diag_add;
+		*(vch*)(o + c0) = a;
+	} else {
+		const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+		if (c >= n) return;
+		T a = o[c];
+		const T b = s[c];
+		a = combine == STPY_OUT_ADD ? a + b : (combine == STPY_OUT_MUL ? a * b : b);
+		if (c == row) a += diag_add;
+		o[c] = a;
+	}
+}
+
+template <typename T>
+int combine_into(int64_t m, int64_t n, T* out, int64_t ldo, const T* src, int64_t lds, int combine, double diag_add, hipStream_t st)
+{
+	if (m <= 0 || n <= 0) return 0;
+	constexpr int CH = 16 / (int)sizeof(T);
+	const int vec = (n % CH == 0) && (ldo % CH == 0) && (lds % CH == 0) && ((((uintptr_t)out | (uintptr_t)src) & 15) == 0);
+	const int64_t per_row = vec ? n / CH : n;
+	// rows ride on gridDim.y (<= 65535 per launch)
+	for (int64_t r0 = 0; r0 < m; r0 += 65535) {
+		const int64_t rows = (m - r0 < 65535) ? (m - r0) : 65535;
+		hipLaunchKernelGGL((combine_kernel<T>), dim3((unsigned)((per_row + 255) / 256), (unsigned)rows), dim3(256), 0, st,
+		                   out, ldo, src, lds, r0, n, combine, (T)diag_add, vec);
+	}
+	return check_launch("combine");
+}
+
+// H = (weight * Kinv - alpha alpha^T) o F, F the derivative factor of the kernel family (see gemm.hip, mode 4); Kinv is the
+// symmetric inverse (n x n).  Hsrc == nullptr: in place over H; otherwise Kinv is read from Hsrc and H only written, so
+// several terms can be formed from one inverse without copying it.  Same workspace layout as gram().
 template <typename T>
 int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, double kappa, double weight,
-               const T* alpha, T* H, int64_t ldh, void* work, hipStream_t st)
+               const T* alpha, const T* Hsrc, int64_t ldhs, T* H, int64_t ldh, void* work, hipStream_t st)
 {
 	if (n <= 0) return 0;
 	if (kind < STPY_K_SE || kind > STPY_K_MATERN52) { set_error("lml_weight: kernel kind %d has no lengthscale gradient", kind); return -1; }
@@ -250,7 +299,8 @@ int lml_weight(int kind, const T* x, int64_t n, int64_t ldx, int d, const int32_
 	int rc = check_launch("lml_weight prep");
 	if (rc) return rc;
 	GramEpilogue<T> epi{kind, 0, (T)kappa, T(0), T(0), na, na, alpha, (T)weight};
-	return gemm_nt<T>(n, n, dpad, as, dpad, as, dpad, H, ldh, (T*)nullptr, 0, 4, 0, st, nullptr, nullptr, &epi);
+	// (mode 4 reads the old tile through C2 when it is set; it never takes the second-copy store)
+	return gemm_nt<T>(n, n, dpad, as, dpad, as, dpad, H, ldh, const_cast<T*>(Hsrc), Hsrc ? ldhs : 0, 4, 0, st, nullptr, nullptr, &epi);
 }
 
 // k(x_i, x_i): stationary kernels give kappa * phi(0); LINEAR gives kappa ||x_i[cols] * inv_ls||^2 + offset,
@@ -288,7 +338,8 @@ int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t
 }
 
 #define INST(T) \
-	template int lml_weight<T>(int, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, const T*, T*, int64_t, void*, hipStream_t); \
+	template int lml_weight<T>(int, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, const T*, const T*, int64_t, T*, int64_t, void*, hipStream_t); \
+	template int combine_into<T>(int64_t, int64_t, T*, int64_t, const T*, int64_t, int, double, hipStream_t); \
 	template int gram<T>(int, const T*, int64_t, int64_t, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, double, int, int, T*, int64_t, void*, hipStream_t); \
 	template int gram_diag<T>(int, const T*, int64_t, int64_t, int, const int32_t*, const T*, double, double, int, T*, hipStream_t);
 INST(double)

@@ -11,6 +11,10 @@
 // workspace P (leading dimension nb) that the left-looking updates and the trailing update read:
 // rows of P are nb*8 bytes apart instead of lda*8, and the GEMM's two operands become the same
 // buffer.  inverse(L_cc) of every diagonal block is kept in `winv` for the triangular solves.
+#include <atomic>
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 namespace stpy {
@@ -407,13 +411,13 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 {
 	const size_t lds_old = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
 	const size_t lds_new = (size_t)(TRI + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
-	static bool attr_set[2] = {false, false};
+	static std::atomic<bool> attr_set[2];          // (idempotent: two threads racing here both set the same attribute values)
 	const int which = sizeof(T) == 8 ? 0 : 1;
-	if (!attr_set[which]) {
+	if (!attr_set[which].load(std::memory_order_acquire)) {
 		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
 		if (e != hipSuccess) { set_error("potf2: hipFuncSetAttribute(%zu B LDS) failed: %s", lds_new, hipGetErrorString(e)); return -1000 - (int)e; }
-		attr_set[which] = true;
+		attr_set[which].store(true, std::memory_order_release);
 	}
 	if (g_potf2_scalar)
 		hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(PT_THREADS), lds_old, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
@@ -422,29 +426,39 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 	return check_launch("potf2_trtri");
 }
 
-// Side stream + events for the look-ahead (one set per process, created on first use; the side
-// stream has the highest priority so the small panel kernels are dispatched ahead of the queued
-// trailing-update workgroups as CU slots free up).
+// Side stream + events for the look-ahead: one set per (device, caller stream), created on first use under a
+// mutex and never destroyed (a process drives a handful of streams).  The side stream has the highest priority so
+// the small panel kernels are dispatched ahead of the queued trailing-update workgroups as CU slots free up.
+// Two host threads on two streams get two sets; calls on one stream are enqueued in program order and the events
+// of a set are only ever recorded / awaited by calls on that stream, so re-use across calls needs no further care.
 int g_potrf_diag_first_below = 8192;     // stpy_tune key 7
-static LookAhead g_la;
+namespace {
+struct LaKey { int device; hipStream_t stream; bool operator<(const LaKey& o) const { return device != o.device ? device < o.device : stream < o.stream; } };
+std::mutex g_la_mutex;
+std::map<LaKey, LookAhead*> g_la_map;
+}
 
-LookAhead* lookahead_state() { return &g_la; }
-
-int lookahead_init()
+int lookahead_acquire(hipStream_t caller, LookAhead** out)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { set_error("potrf: hipGetDevice failed"); return -1001; }
-	if (g_la.side && g_la.device == dev) return 0;
+	std::lock_guard<std::mutex> lock(g_la_mutex);
+	const LaKey key{dev, caller};
+	auto it = g_la_map.find(key);
+	if (it != g_la_map.end()) { *out = it->second; return 0; }
+	LookAhead* la = new LookAhead();
 	int lo = 0, hi = 0;
 	(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-	if (hipStreamCreateWithPriority(&g_la.side, hipStreamNonBlocking, hi) != hipSuccess ||
-	    hipEventCreateWithFlags(&g_la.col_ready, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&g_la.panel_done, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&g_la.trail_done, hipEventDisableTiming) != hipSuccess) {
+	if (hipStreamCreateWithPriority(&la->side, hipStreamNonBlocking, hi) != hipSuccess ||
+	    hipEventCreateWithFlags(&la->col_ready, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&la->panel_done, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&la->trail_done, hipEventDisableTiming) != hipSuccess) {
 		set_error("potrf: could not create the look-ahead stream/events");
+		delete la;
 		return -1002;
 	}
-	g_la.device = dev;
+	g_la_map[key] = la;
+	*out = la;
 	return 0;
 }
 
@@ -453,7 +467,7 @@ int lookahead_init()
 // panel workspace P (n x nb, leading dimension nb, rows indexed globally).
 template <typename T>
 static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* winv, T* P, int64_t ldp, int32_t* info, hipStream_t st,
-                        hipEvent_t first_diag = nullptr)
+                        int gflags, hipEvent_t first_diag = nullptr)
 {
 	int rc;
 	for (int64_t c = k; c < k + kb; c += IB) {
@@ -461,7 +475,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 		const int64_t jj = c - k;
 		if (jj > 0) {       // A[c:n, c:c+cb] -= P[c:n, 0:jj] P[c:c+cb, 0:jj]^T
 			ProfScope ps(TAG_PANEL_GEMM, 2.0 * (double)(n - c) * (double)cb * (double)jj, st);
-			rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st);
+			rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 			if (rc) return rc;
 		}
 		{
@@ -473,7 +487,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 		if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
 			ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
 			rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
-			                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st);
+			                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 			if (rc) return rc;
 		}
 	}
@@ -491,7 +505,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 // The two regions written concurrently are disjoint (columns [r, r+nb) vs columns >= r+nb) and the
 // trailing update reads only Pk, which the side stream never touches.
 template <typename T>
-int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st)
+int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st, int gflags)
 {
 	// nb = 0: the panel width follows the size of what is LEFT (potrf_auto_nb): wide panels while the trailing
 	// update is long enough to hide the next panel's latency-bound chain, narrower ones towards the end
@@ -501,13 +515,14 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 	HIPCHK(hipMemsetAsync(info, 0, sizeof(int32_t), st));
 	const int64_t ldp = nb;                                         // widest panel (the first one)
 	T* Pbuf[2] = {work, work + n * ldp};
-	int rc = lookahead_init();
+	LookAhead* la = nullptr;
+	int rc = lookahead_acquire(st, &la);
 	if (rc) return rc;
-	hipStream_t side = g_la.side;
+	hipStream_t side = la->side;
 	auto width = [&](int64_t left) { const int64_t w = adaptive ? potrf_auto_nb(left) : nb; return left < w ? left : w; };
 
 	int64_t wk = width(n);                                          // width of the current panel
-	rc = factor_panel<T>(n, 0, wk, A, lda, winv, Pbuf[0], ldp, info, st);
+	rc = factor_panel<T>(n, 0, wk, A, lda, winv, Pbuf[0], ldp, info, st, gflags);
 	if (rc) return rc;
 	int cur = 0;
 	for (int64_t k = 0; k + wk < n;) {
@@ -519,23 +534,23 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 			rc = gemm_nt<T>(n - r, nkb, wk, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, st);
 			if (rc) return rc;
 		}
-		HIPCHK(hipEventRecord(g_la.col_ready, st));
-		HIPCHK(hipStreamWaitEvent(side, g_la.col_ready, 0));
+		HIPCHK(hipEventRecord(la->col_ready, st));
+		HIPCHK(hipStreamWaitEvent(side, la->col_ready, 0));
 		// A short trailing update cannot hide the panel chain, and the chain's first kernel -- one workgroup that needs
 		// 83 KiB of LDS -- waits ~200 us for a CU slot once the update's workgroups have flooded the chip (kernel trace,
 		// tools/potrf_only.py).  Below the threshold the update therefore starts only after that kernel has run.
 		const bool diag_first = (n - r) <= g_potrf_diag_first_below;
-		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, diag_first ? g_la.trail_done : nullptr);
+		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, gflags, diag_first ? la->trail_done : nullptr);
 		if (rc) return rc;
-		HIPCHK(hipEventRecord(g_la.panel_done, side));
-		if (diag_first) HIPCHK(hipStreamWaitEvent(st, g_la.trail_done, 0));
+		HIPCHK(hipEventRecord(la->panel_done, side));
+		if (diag_first) HIPCHK(hipStreamWaitEvent(st, la->trail_done, 0));
 		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
 			const int64_t r2 = r + nkb;
 			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, st);      // lower triangle: m^2 k
 			rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, st);
 			if (rc) return rc;
 		}
-		HIPCHK(hipStreamWaitEvent(st, g_la.panel_done, 0));
+		HIPCHK(hipStreamWaitEvent(st, la->panel_done, 0));
 		// the side stream may not start overwriting workspace `cur` (panel k+2) before this
 		// trailing update has finished reading it: it waits on the next col_ready, which is
 		// recorded on `st` after this update -- stream order gives that for free.
@@ -548,7 +563,7 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 
 template int potf2_trtri<double>(double*, int64_t, int, double*, double*, int64_t, int32_t*, int, hipStream_t);
 template int potf2_trtri<float>(float*, int64_t, int, float*, float*, int64_t, int32_t*, int, hipStream_t);
-template int potrf<double>(int64_t, double*, int64_t, double*, double*, int, int32_t*, hipStream_t);
-template int potrf<float>(int64_t, float*, int64_t, float*, float*, int, int32_t*, hipStream_t);
+template int potrf<double>(int64_t, double*, int64_t, double*, double*, int, int32_t*, hipStream_t, int);
+template int potrf<float>(int64_t, float*, int64_t, float*, float*, int, int32_t*, hipStream_t, int);
 
 }  // namespace stpy

@@ -21,23 +21,27 @@ int g_rff_tile = 1;             // dedicated fp32 kernels (stpy_tune key 9): 1 =
                                 // the other d = 32 / 64 shapes; 2 = tile kernel only; 0 = always the GEMM epilogue
 
 __global__ __launch_bounds__(256)
-void rff_trig_f64_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias, double scale)
+void rff_trig_f64_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias,
+                         const double* __restrict__ fscale, double scale)
 {
 	const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	const int64_t total = n * (int64_t)(m / 2);
+	const int mp = (m + 1) / 2;                           // feature pairs per row (an odd m -- cosine-only quadrature grids -- leaves a single)
+	const int64_t total = n * (int64_t)mp;
 	if (idx >= total) return;
-	const int64_t i = idx / (m / 2);
-	const int j = (int)(idx - i * (m / 2)) * 2;           // two adjacent features per thread: 16-byte accesses
+	const int64_t i = idx / mp;
+	const int j = (int)(idx - i * mp) * 2;                // two adjacent features per thread
 	double* o = out + i * ldo + j;
-	double q0 = o[0], q1 = o[1];
-	if (bias) { q0 += bias[j]; q1 += bias[j + 1]; }
-	o[0] = scale * ((bias || j < half) ? cos(q0) : sin(q0));
-	o[1] = scale * ((bias || j + 1 < half) ? cos(q1) : sin(q1));
+	const bool two = j + 1 < m;
+	double q0 = o[0], q1 = two ? o[1] : 0.0;
+	if (bias) { q0 += bias[j]; if (two) q1 += bias[j + 1]; }
+	o[0] = scale * (fscale ? fscale[j] : 1.0) * ((bias || j < half) ? cos(q0) : sin(q0));
+	if (two) o[1] = scale * (fscale ? fscale[j + 1] : 1.0) * ((bias || j + 1 < half) ? cos(q1) : sin(q1));
 }
 
 // transposed embedding Phi^T (m x n): the feature index is the row
 __global__ __launch_bounds__(256)
-void rff_trig_f64_t_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias, double scale)
+void rff_trig_f64_t_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int m, int half, const double* __restrict__ bias,
+                           const double* __restrict__ fscale, double scale)
 {
 	const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	if (idx >= (int64_t)m * n) return;
@@ -45,7 +49,7 @@ void rff_trig_f64_t_kernel(double* __restrict__ out, int64_t ldo, int64_t n, int
 	const int64_t i = idx - (int64_t)j * n;
 	double q = out[(int64_t)j * ldo + i];
 	if (bias) q += bias[j];
-	out[(int64_t)j * ldo + i] = scale * ((bias || j < half) ? cos(q) : sin(q));
+	out[(int64_t)j * ldo + i] = scale * (fscale ? fscale[j] : 1.0) * ((bias || j < half) ? cos(q) : sin(q));
 }
 
 // ---- fp32, d = 32 or 64, tile-aligned shapes: 128 x 64 output tile per workgroup, the whole contraction
@@ -273,15 +277,18 @@ void rff_stream_f32_kernel(const float* __restrict__ x, int64_t ldx, const float
 
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
-              const T* bias, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
+              const T* bias, const T* feat_scale, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
 
+// (an odd m only makes sense without the cos | sin split: biased features, or cosine-only quadrature grids that pass a
+// zero bias -- embedding.py:84-85 demands an even m for everything else)
 template <>
 int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float* W, int64_t ldw, int64_t m,
-                     const float* bias, double scale, float* out, int64_t ldo, int transposed, hipStream_t st)
+                     const float* bias, const float* feat_scale, double scale, float* out, int64_t ldo, int transposed, hipStream_t st)
 {
 	if (n <= 0 || m <= 0) return 0;
-	if (m % 2 != 0) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
-	if (g_rff_tile >= 1 && g_rff_tile != 2 && !transposed && d == 64 && n % 128 == 0 && m % 1024 == 0 && n >= 8192 && ldw < ((int64_t)1 << 27) && ldo < ((int64_t)1 << 28) && ldx % 4 == 0 && ldw % 4 == 0 &&
+	if (m % 2 != 0 && !bias) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
+	// per-feature amplitudes (quadrature embeddings: m is small there) take the GEMM-epilogue route
+	if (!feat_scale && g_rff_tile >= 1 && g_rff_tile != 2 && !transposed && d == 64 && n % 128 == 0 && m % 1024 == 0 && n >= 8192 && ldw < ((int64_t)1 << 27) && ldo < ((int64_t)1 << 28) && ldx % 4 == 0 && ldw % 4 == 0 &&
 	    ldo % 4 == 0 && (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out) & 15) == 0 && n / 128 < (int64_t)INT32_MAX && m < (int64_t)INT32_MAX) {
 		const int row_blocks = (int)(n / 128);
 		int wgs = 512;                                                   // two per CU; a multiple of eight (one column part per XCD)
@@ -289,7 +296,7 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 		hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
 		return check_launch("rff_stream_f32");
 	}
-	if (g_rff_tile && !transposed && (d == 32 || d == 64) && n % 128 == 0 && m % 64 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
+	if (!feat_scale && g_rff_tile && !transposed && (d == 32 || d == 64) && n % 128 == 0 && m % 64 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
 	    (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0 && (n / 128) * (m / 64) < (int64_t)INT32_MAX && m < (int64_t)INT32_MAX) {
 		const int col_tiles = (int)(m / 64);
 		const dim3 grid((unsigned)((n / 128) * col_tiles));
@@ -297,29 +304,29 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 		else         hipLaunchKernelGGL(rff_tile_f32_kernel<32>, grid, dim3(256), 0, st, x, ldx, W, ldw, out, ldo, col_tiles, (int)(m / 2), bias, (float)scale, g_gemm_exp);
 		return check_launch("rff_tile_f32");
 	}
-	RffEpilogue<float> epi{(int)(m / 2), (float)scale, bias, transposed ? 1 : 0};
+	RffEpilogue<float> epi{(int)(m / 2), (float)scale, bias, transposed ? 1 : 0, feat_scale};
 	if (transposed) return gemm_nt<float>(m, n, d, W, ldw, x, ldx, out, ldo, (float*)nullptr, 0, 2, 0, st, nullptr, &epi);
 	return gemm_nt<float>(n, m, d, x, ldx, W, ldw, out, ldo, (float*)nullptr, 0, 2, 0, st, nullptr, &epi);
 }
 
 template <>
 int rff_embed<double>(const double* x, int64_t n, int64_t ldx, int d, const double* W, int64_t ldw, int64_t m,
-                      const double* bias, double scale, double* out, int64_t ldo, int transposed, hipStream_t st)
+                      const double* bias, const double* feat_scale, double scale, double* out, int64_t ldo, int transposed, hipStream_t st)
 {
 	if (n <= 0 || m <= 0) return 0;
-	if (m % 2 != 0) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
+	if (m % 2 != 0 && !bias) { set_error("rff_embed: m must be even (embedding.py:84-85)"); return -8; }
 	if (m > INT32_MAX) { set_error("rff_embed: m exceeds int32"); return -7; }
 	if (transposed) {
 		int rc = gemm_nt<double>(m, n, d, W, ldw, x, ldx, out, ldo, (double*)nullptr, 0, 0, 0, st);
 		if (rc) return rc;
 		const int64_t total = m * n;
-		hipLaunchKernelGGL(rff_trig_f64_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, ldo, n, (int)m, (int)(m / 2), bias, scale);
+		hipLaunchKernelGGL(rff_trig_f64_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, ldo, n, (int)m, (int)(m / 2), bias, feat_scale, scale);
 		return check_launch("rff_trig_f64_t");
 	}
 	int rc = gemm_nt<double>(n, m, d, x, ldx, W, ldw, out, ldo, (double*)nullptr, 0, 0, 0, st);
 	if (rc) return rc;
-	const int64_t total = n * (m / 2);
-	hipLaunchKernelGGL(rff_trig_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, ldo, n, (int)m, (int)(m / 2), bias, scale);
+	const int64_t total = n * ((m + 1) / 2);
+	hipLaunchKernelGGL(rff_trig_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, ldo, n, (int)m, (int)(m / 2), bias, feat_scale, scale);
 	return check_launch("rff_trig_f64");
 }
 

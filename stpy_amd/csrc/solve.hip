@@ -14,7 +14,7 @@ namespace stpy {
 // n^3/3 flops instead of n^3.
 // the 128-column blocks of one nb-wide panel, left-looking (small, latency-bound launches)
 template <typename T>
-static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs)
+static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int gflags)
 {
 	int rc;
 	for (int64_t c = k; c < k + kb; c += IB) {
@@ -23,13 +23,13 @@ static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, 
 		const int64_t mc = upper_rhs ? ((c + cb < m) ? c + cb : m) : m;       // rows that can be non-zero in this block column
 		if (jj > 0) {   // B[:, c:c+cb] -= B[:, k:c] L[c:c+cb, k:c]^T
 			ProfScope ps(TAG_TRSM_GEMM, 2.0 * (double)mc * (double)cb * (double)jj, st);
-			rc = gemm_nt<T>(mc, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st);
+			rc = gemm_nt<T>(mc, cb, jj, B + k, ldb, L + c * ldl + k, ldl, B + c, ldb, (T*)nullptr, 0, 1, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 			if (rc) return rc;
 		}
 		// B[:, c:c+cb] <- B[:, c:c+cb] inverse(L_cc)^T   (one column tile => safe in place)
 		{
 			ProfScope ps(TAG_TRSM_GEMM, (double)mc * (double)cb * (double)cb, st);
-			rc = gemm_nt<T>(mc, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st);
+			rc = gemm_nt<T>(mc, cb, cb, B + c, ldb, winv + (c / IB) * IB * IB, IB, B + c, ldb, (T*)nullptr, 0, 0, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 		}
 		if (rc) return rc;
 	}
@@ -42,14 +42,14 @@ static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, 
 // solved, the update of the NEXT panel's columns goes first, then the next panel's latency-bound
 // 128-blocks run on the side stream while the caller's stream updates the remaining columns.
 template <typename T>
-static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs)
+static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs, int gflags)
 {
 	if (nb <= 0) nb = TRSM_DEFAULT_NB;
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
-	int rc = lookahead_init();
+	LookAhead* la = nullptr;
+	int rc = lookahead_acquire(st, &la);
 	if (rc) return rc;
-	LookAhead* la = lookahead_state();
-	rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs);
+	rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs, gflags);
 	if (rc) return rc;
 	for (int64_t k = 0; k + nb < n; k += nb) {
 		const int64_t r = k + nb;
@@ -62,7 +62,7 @@ static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, con
 		}
 		HIPCHK_S(hipEventRecord(la->col_ready, st));
 		HIPCHK_S(hipStreamWaitEvent(la->side, la->col_ready, 0));
-		rc = solve_panel<T>(m, n, r, nkb, L, ldl, winv, B, ldb, la->side, upper_rhs);
+		rc = solve_panel<T>(m, n, r, nkb, L, ldl, winv, B, ldb, la->side, upper_rhs, gflags);
 		if (rc) return rc;
 		HIPCHK_S(hipEventRecord(la->panel_done, la->side));
 		if (r + nkb < n) {  // the rest: B[:, r+nkb:] -= B[:, k:r] L[r+nkb:, k:r]^T
@@ -82,12 +82,12 @@ static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, con
 // deepest levels, half of all flops in the top-level product alone), solve the right part.  Everything is
 // in order on the caller's stream; the leaves are single 128-blocks.
 template <typename T>
-static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int64_t leaf)
+static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int64_t leaf, int gflags)
 {
-	if (w <= leaf) return solve_panel<T>(m, n, c0, w, L, ldl, winv, B, ldb, st, upper_rhs);
+	if (w <= leaf) return solve_panel<T>(m, n, c0, w, L, ldl, winv, B, ldb, st, upper_rhs, gflags);
 	int64_t h = IB;
 	while (h * 2 < w) h *= 2;                                 // largest power-of-two multiple of 128 below w
-	int rc = trsm_recursive<T>(m, n, c0, h, L, ldl, winv, B, ldb, st, upper_rhs, leaf);
+	int rc = trsm_recursive<T>(m, n, c0, h, L, ldl, winv, B, ldb, st, upper_rhs, leaf, gflags);
 	if (rc) return rc;
 	const int64_t mr = upper_rhs ? ((c0 + h < m) ? c0 + h : m) : m;      // X[:, c0:c0+h) is zero from row c0+h on
 	{
@@ -95,7 +95,7 @@ static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* 
 		rc = gemm_nt<T>(mr, w - h, h, B + c0, ldb, L + (c0 + h) * ldl + c0, ldl, B + c0 + h, ldb, (T*)nullptr, 0, 1, 0, st);
 		if (rc) return rc;
 	}
-	return trsm_recursive<T>(m, n, c0 + h, w - h, L, ldl, winv, B, ldb, st, upper_rhs, leaf);
+	return trsm_recursive<T>(m, n, c0 + h, w - h, L, ldl, winv, B, ldb, st, upper_rhs, leaf, gflags);
 }
 
 // LEFT-looking between panels: panel p (columns [k, k+nb)) first receives every earlier panel's
@@ -120,7 +120,7 @@ int trsm_auto_nb(int64_t)
 }
 
 template <typename T>
-int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs, T* work)
+int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs, T* work, int gflags)
 {
 	// no workspace: the long products cannot be cut into K passes, and one round of workgroups that
 	// holds every CU slot would keep the next panel's small kernels out -- the right-looking sweep
@@ -133,15 +133,15 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 	// a large product on a second stream (and split K), stay ahead (n = 65536, M = 1024: 97 vs 107 ms).
 	// (not for the triangular right-hand side of the inverse: value + gradient at N = 32768 0.615 s with the sweep, 0.677 s recursive)
 	if (g_trsm_right_looking >= 3 || (g_trsm_right_looking == 0 && m >= 2048 && !upper_rhs))
-		return trsm_recursive<T>(m, n, 0, n, L, ldl, winv, B, ldb, st, upper_rhs, g_trsm_right_looking >= 3 ? (int64_t)IB << (g_trsm_right_looking - 3) : 2 * IB);
-	if (g_trsm_right_looking == 1 || !work || (n < 32768 && g_trsm_right_looking != 2)) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs);
+		return trsm_recursive<T>(m, n, 0, n, L, ldl, winv, B, ldb, st, upper_rhs, g_trsm_right_looking >= 3 ? (int64_t)IB << (g_trsm_right_looking - 3) : 2 * IB, gflags);
+	if (g_trsm_right_looking == 1 || !work || (n < 32768 && g_trsm_right_looking != 2)) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs, gflags);
 	if (nb <= 0) nb = trsm_auto_nb(m);
 	if (nb % IB != 0) { set_error("trsm: nb must be a multiple of %d", IB); return -9; }
-	int rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs);
+	int rc = solve_panel<T>(m, n, 0, (n < nb) ? n : nb, L, ldl, winv, B, ldb, st, upper_rhs, gflags);
 	if (rc || n <= nb) return rc;
-	rc = lookahead_init();
+	LookAhead* la = nullptr;
+	rc = lookahead_acquire(st, &la);
 	if (rc) return rc;
-	LookAhead* la = lookahead_state();
 	hipStream_t side = la->side;
 	HIPCHK_S(hipEventRecord(la->col_ready, st));            // "G1(1)" is empty: panel 1 only waits for S(0)
 	for (int64_t k = nb; k < n; k += nb) {
@@ -154,7 +154,7 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 			rc = gemm_nt<T>(mr, w, nb, B + (k - nb), ldb, L + k * ldl + (k - nb), ldl, B + k, ldb, (T*)nullptr, 0, 1, 0, side);
 			if (rc) return rc;
 		}
-		rc = solve_panel<T>(m, n, k, w, L, ldl, winv, B, ldb, side, upper_rhs);
+		rc = solve_panel<T>(m, n, k, w, L, ldl, winv, B, ldb, side, upper_rhs, gflags);
 		if (rc) return rc;
 		// ---- caller's stream: G1(p+1) over columns [0, k): needs S(p-1), not S(p)
 		if (k > nb) HIPCHK_S(hipStreamWaitEvent(st, la->panel_done, 0));
@@ -398,6 +398,30 @@ int predict(int64_t m, int64_t n, const T* X, int64_t ldx, const T* z, const T* 
 	return check_launch("predict");
 }
 
+// Second half of the prediction epilogue when X is column-sharded across ranks: the partial sums <X_i, z> and <X_i, X_i>
+// have been all-reduced by the caller; every process row held a replica, hence `scale` = 1 / P_r.
+template <typename T>
+__global__ __launch_bounds__(256)
+void predict_finish_kernel(int64_t m, T* __restrict__ mu, const T* __restrict__ sumsq, const T* __restrict__ kdiag, T scale, T* __restrict__ sigma, int clamp)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= m) return;
+	if (mu) mu[i] *= scale;
+	if (sigma) {
+		T var = kdiag[i] - scale * sumsq[i];
+		if (clamp && var < T(0)) var = T(0);
+		sigma[i] = sqrt(var);
+	}
+}
+
+template <typename T>
+int predict_finish(int64_t m, T* mu, const T* sumsq, const T* kdiag, double scale, T* sigma, int clamp, hipStream_t st)
+{
+	if (m <= 0) return 0;
+	hipLaunchKernelGGL((predict_finish_kernel<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, mu, sumsq, kdiag, (T)scale, sigma, clamp);
+	return check_launch("predict_finish");
+}
+
 // ------------------------------------------------------------------------------------------
 // out2[0] = sum log L_ii, out2[1] = z^T z.  Single workgroup, fixed summation order (bitwise
 // reproducible run to run).
@@ -464,11 +488,12 @@ int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st)
 }
 
 #define INST(T) \
-	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t, bool, T*); \
+	template int trsm_right_lt<T>(int64_t, int64_t, const T*, int64_t, const T*, T*, int64_t, int, hipStream_t, bool, T*, int); \
 	template int potri_lower<T>(int64_t, const T*, int64_t, const T*, T*, int64_t, T*, hipStream_t); \
 	template int trsv<T>(int64_t, const T*, int64_t, const T*, T*, T*, int, hipStream_t); \
 	template int predict<T>(int64_t, int64_t, const T*, int64_t, const T*, const T*, T*, T*, int, hipStream_t); \
 	template int logdet_quad<T>(int64_t, const T*, int64_t, const T*, T*, hipStream_t); \
+	template int predict_finish<T>(int64_t, T*, const T*, const T*, double, T*, int, hipStream_t); \
 	template int symmetrize_lower<T>(int64_t, T*, int64_t, hipStream_t);
 INST(double)
 INST(float)

@@ -10,6 +10,7 @@ Same constructor arguments, same ``kernel(a, b, **kwargs) -> (|b|, |a|)`` orient
 arithmetic runs in ``stpy_gram`` (stpy_amd/csrc/gram.hip); there is no CPU path.
 """
 import math
+from collections import OrderedDict
 
 import torch
 
@@ -23,7 +24,8 @@ _OUT_OF_SCOPE = ("laplace", "modified_matern", "custom", "tanh", "step", "angsim
 
 _MATERN_KIND = {0.5: _lib.K_MATERN12, 1.5: _lib.K_MATERN32, 2.5: _lib.K_MATERN52}
 
-_const_cache = {}
+_const_cache = OrderedDict()
+_CONST_CACHE_ENTRIES = 4096
 
 
 def _scalar(v):
@@ -34,15 +36,25 @@ def _scalar(v):
 
 
 def _dev_const(values, dtype, device, int32=False):
-	"""Small constant device arrays (inverse lengthscales, column indices), cached by value."""
+	"""Small constant device arrays (inverse lengthscales, column indices), cached by value.
+	Least-recently-used entries are dropped one at a time (a hyper-parameter search creates a new lengthscale key on
+	every evaluation); an entry used from a stream other than the one it was allocated on is recorded on that stream,
+	so the caching allocator does not hand its block out again while kernels queued there may still read it."""
 	key = (tuple(values), dtype if not int32 else "i32", device.index)
-	t = _const_cache.get(key)
-	if t is None:
-		if len(_const_cache) > 4096:
-			_const_cache.clear()
+	cur = torch.cuda.current_stream(device)
+	ent = _const_cache.get(key)
+	if ent is None:
+		while len(_const_cache) >= _CONST_CACHE_ENTRIES:
+			_const_cache.popitem(last=False)
 		t = torch.tensor(list(values), dtype=torch.int32 if int32 else dtype, device=device)
-		_const_cache[key] = t
-	return t
+		ent = (t, {cur.cuda_stream})
+		_const_cache[key] = ent
+	else:
+		_const_cache.move_to_end(key)
+		if cur.cuda_stream not in ent[1]:
+			ent[0].record_stream(cur)
+			ent[1].add(cur.cuda_stream)
+	return ent[0]
 
 
 class KernelFunction:
@@ -295,10 +307,11 @@ class KernelFunction:
 		items = self._resolve(dict(kwargs) if kwargs else {})
 		return self._run_items(items, a, b, out, diag_add, lower_only)
 
-	def _run_items(self, items, a, b, out, diag_add=0.0, lower_only=False):
-		"""Evaluates a list of resolved items (the first one's operation is taken as "set") into ``out``."""
+	def _run_items(self, items, a, b, out, diag_add=0.0, lower_only=False, first_is_set=True):
+		"""Evaluates a list of resolved items into ``out``.  The first one's operation is taken as "set" unless
+		``first_is_set`` is False (then ``out`` already holds a value the chain continues from)."""
 		lib = _lib.load()
-		if items and items[0]['op'] != "-":
+		if first_is_set and items and items[0]['op'] != "-":
 			items = [dict(items[0], op="-")] + list(items[1:])
 		dt = _lib.dtype_code(out.dtype)
 		n, q = a.shape[0], b.shape[0]
@@ -326,10 +339,9 @@ class KernelFunction:
 							   diag_add if (last and not l['fold']) else 0.0, 1 if lower_only else 0, l['combine'],
 							   _lib.ptr(target), target.stride(0), _lib.ptr(work), work.numel() * work.element_size(), _lib.stream_ptr())
 			_lib.check(rc, "stpy_gram")
-			if l['fold']:
-				out.mul_(tmp)
-				if last and diag_add != 0.0:
-					out.diagonal().add_(diag_add)
+			if l['fold']:       # out *= (sum of the item's terms), then the noise term if this was the last launch
+				_lib.check(lib.stpy_combine(dt, q, n, _lib.ptr(out), out.stride(0), _lib.ptr(tmp), tmp.stride(0), _lib.OUT_MUL,
+											diag_add if last else 0.0, _lib.stream_ptr()), "stpy_combine")
 		return out
 
 	@staticmethod
@@ -373,7 +385,8 @@ class KernelFunction:
 									_lib.ptr(inv_ls), t['kappa'], t['offset'], l['combine'], _lib.ptr(target), _lib.stream_ptr())
 			_lib.check(rc, "stpy_gram_diag")
 			if l['fold']:
-				out.mul_(tmp)
+				_lib.check(lib.stpy_combine(dt, 1, out.shape[0], _lib.ptr(out), out.shape[0], _lib.ptr(tmp), tmp.shape[0], _lib.OUT_MUL, 0.0,
+											_lib.stream_ptr()), "stpy_combine")
 		return out
 
 	def kernel_self_diag(self, x, **kwargs):

@@ -74,20 +74,18 @@ class HipLocalOps:
 		self.dtype = dtype
 		self.code = _lib.dtype_code(dtype)
 		self.nb = nb
+		self.flags = 0
 
 	def empty(self, *shape):
 		return torch.empty(shape, dtype=self.dtype, device=self.device)
 
 	def beside_update(self, on):
-		"""Brackets the launches of a panel step that is enqueued while the trailing update occupies the chip.
+		"""Brackets the launches of a panel step that is enqueued while the trailing update occupies the chip:
+		potrf / trsm_right_lt below then pass STPY_FLAG_BESIDE_UPDATE (a per-call flag, no process-wide switch).
 		The one-volley K = 128 kernel holds 128 KiB of LDS, i.e. it needs a CU with no update workgroup on
 		it, and without preemption it then waits for the update's grid to drain (13.8 ms for a 14-workgroup
 		product in the trace of N = 65 536); the 32 KiB kernels fit beside one update workgroup."""
-		if on:
-			self._k128_saved = int(self.lib.stpy_tune_get(8))
-			self.lib.stpy_tune(8, 0)
-		else:
-			self.lib.stpy_tune(8, self._k128_saved)
+		self.flags = _lib.FLAG_BESIDE_UPDATE if on else 0
 
 	def zeros(self, *shape):
 		return torch.zeros(shape, dtype=self.dtype, device=self.device)
@@ -110,8 +108,7 @@ class HipLocalOps:
 		winv = self.empty(int(self.lib.stpy_potrf_winv_elems(n)))
 		work = torch.empty((int(self.lib.stpy_potrf_workspace_bytes(self.code, n, self.nb)),), dtype=torch.uint8, device=self.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=self.device)
-		_lib.check(self.lib.stpy_potrf(self.code, n, _lib.ptr(A), A.stride(0), _lib.ptr(winv), _lib.ptr(work), work.numel() * work.element_size(), self.nb,
-									   _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
+		_lib.check(self.lib.stpy_potrf(self.code, n, _lib.ptr(A), A.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, self.flags, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
 		return winv, info
 
 	def trsm_right_lt(self, B, L, winv):
@@ -119,8 +116,8 @@ class HipLocalOps:
 		m, n = B.shape
 		if m == 0:
 			return
-		_lib.check(self.lib.stpy_trsm_right_lt(self.code, m, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), _lib.ptr(B), B.stride(0),
-											   self.nb, None, 0, _lib.stream_ptr()), "stpy_trsm_right_lt")
+		_lib.check(self.lib.stpy_trsm_right_lt(self.code, m, n, _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(B), B.stride(0),
+											   self.nb, self.flags, None, 0, _lib.stream_ptr()), "stpy_trsm_right_lt")
 
 	def gemm_nt(self, A, B, C, mode, bc=None):
 		"""C (mode 0: =, 1: -=) A B^T.  bc = (nb_dist, pr, pc, myr, myc, i0, j0) enables the staircase."""
@@ -142,15 +139,25 @@ class HipLocalOps:
 										  mode, *[int(v) for v in bc], _lib.stream_ptr())
 		_lib.check(rc, "stpy_gemm_nt")
 
-	def row_sums(self, X, z):
-		"""(sum_k X[i,k] z[k], sum_k X[i,k]^2) for every row of the strided view X."""
+	def row_sums(self, X, z, out=None):
+		"""(sum_k X[i,k] z[k], sum_k X[i,k]^2) for every row of the strided view X; ``out``: a contiguous (2, m) buffer."""
 		m, n = X.shape
-		s1, s2 = self.empty(m), self.empty(m)
+		if out is None:
+			out = self.empty(2, m)
+		s1, s2 = out[0], out[1]
 		if n == 0:
-			return s1.zero_(), s2.zero_()
+			out.zero_()
+			return s1, s2
 		_lib.check(self.lib.stpy_predict(self.code, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(z), None, _lib.ptr(s1), _lib.ptr(s2), 2,
 										 _lib.stream_ptr()), "stpy_predict")
 		return s1, s2
+
+	def predict_finish(self, mu, sumsq, kdiag, scale, clamp):
+		"""mu *= scale (in place); sigma = sqrt(kdiag - scale * sumsq): the epilogue after the all-reduce of the partial sums."""
+		sigma = self.empty(mu.shape[0])
+		_lib.check(self.lib.stpy_predict_finish(self.code, mu.shape[0], _lib.ptr(mu), _lib.ptr(sumsq), _lib.ptr(kdiag), float(scale), _lib.ptr(sigma),
+												1 if clamp else 0, _lib.stream_ptr()), "stpy_predict_finish")
+		return mu, sigma
 
 	def logdet(self, L):
 		"""sum_i log L_ii of the (strided) factor block L."""
@@ -459,15 +466,13 @@ class DistributedGaussianProcess:
 		ops = self.ops
 		xt = ops.to_device(xtest)
 		Xloc = self._solve_rows(None, xt)
-		s1, s2 = ops.row_sums(Xloc[:, :self.nc * self.NB], self._zloc.reshape(-1))
-		red = torch.stack([s1, s2])
+		red = ops.empty(2, xt.shape[0])
+		ops.row_sums(Xloc[:, :self.nc * self.NB], self._zloc.reshape(-1), out=red)
 		self._allreduce(red, dist.ReduceOp.SUM)
-		red /= self.Pr                                  # every process row holds a replica of its columns
 		kd = ops.kdiag(self.kernel_object, xt)
-		var = kd - red[1]
-		if self.clamp_variance:
-			var = var.clamp(min=0)
-		return (_lib.like_input(red[0].reshape(-1, 1), xtest), _lib.like_input(torch.sqrt(var).reshape(-1, 1), xtest))
+		# every process row holds a replica of its columns: scale = 1 / P_r; mu in place, sigma = sqrt(kd - scale * sumsq)
+		mu, sigma = ops.predict_finish(red[0], red[1], kd, 1.0 / self.Pr, self.clamp_variance)
+		return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(sigma.reshape(-1, 1), xtest))
 
 	mean_var = mean_std
 

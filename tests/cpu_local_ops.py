@@ -97,8 +97,19 @@ class CpuLocalOps:
 				rs, cs = slice(ti * IB, min(m, ti * IB + IB)), slice(tj * IB, min(n, tj * IB + IB))
 				C[rs, cs] = prod[rs, cs] if mode == 0 else C[rs, cs] - prod[rs, cs]
 
-	def row_sums(self, X, z):
-		return X @ z, (X * X).sum(dim=1)
+	def row_sums(self, X, z, out=None):
+		if out is None:
+			out = self.empty(2, X.shape[0])
+		out[0] = X @ z
+		out[1] = (X * X).sum(dim=1)
+		return out[0], out[1]
+
+	def predict_finish(self, mu, sumsq, kdiag, scale, clamp):
+		mu *= scale
+		var = kdiag - scale * sumsq
+		if clamp:
+			var = var.clamp(min=0)
+		return mu, torch.sqrt(var)
 
 	def logdet(self, L):
 		return torch.log(torch.diagonal(L)).sum()

@@ -364,6 +364,61 @@ def main():
 	save("K2_more_kernels", a=a, b=b, x7=x7, groups_flat=np.array([0, 1, -1, 2, -1, 3, 4]), p_ard_gamma=N(ag), p_gamma_per_group=np.array(gpg),
 		 p_ard_per_group=N(apg), gp_x=x, gp_y=y, gp_xtest=xtest, gp_mu=N(mu), gp_std=N(std), gp_lml=lml(GP), **out)
 
+	# ---------------------------------------------------------------- Q1: quadrature / Hermite embeddings (embedding.py:250-707)
+	import stpy.embeddings.embedding as E
+	rngq = np.random.RandomState(20241104)
+	out = {}
+	x1 = rngq.uniform(-1, 1, size=(37, 1))
+	x2 = rngq.uniform(-1, 1, size=(29, 2))
+	x3 = rngq.uniform(-1, 1, size=(11, 3))
+	cases = [
+		("hermite_d1", E.HermiteEmbedding, dict(gamma=0.4, m=32, d=1, kappa=1.0), x1),
+		("hermite_d2", E.HermiteEmbedding, dict(gamma=0.7, m=128, d=2, kappa=2.5), x2),
+		("hermite_d3", E.HermiteEmbedding, dict(gamma=1.1, m=2 * 4 ** 3, d=3, kappa=1.0), x3),
+		("hermite_ones", E.HermiteEmbedding, dict(gamma=0.5, m=16, d=1, ones=True), x1),
+		("hermite_cosarg", E.HermiteEmbedding, dict(gamma=0.5, m=16, d=1, cosine=True), x1),      # keyword is reset by the base class
+		("quad_d1", E.QuadratureEmbedding, dict(gamma=0.3, m=40, d=1, kappa=1.3), x1),
+		("quad_d2_scale", E.QuadratureEmbedding, dict(gamma=0.6, m=72, d=2, scale=2.0), x2),
+		("quad_cos_d1", E.QuadratureEmbedding, dict(gamma=0.3, m=22, d=1, cosine=True), x1),
+		("quad_cos_d2", E.QuadratureEmbedding, dict(gamma=0.6, m=26, d=2, cosine=True), x2),       # q = 5: an ODD number of features
+		("trapezoidal_d1", E.TrapezoidalEmbedding, dict(gamma=0.8, m=24, d=1), x1),
+		("clenshaw_d1", E.ClenshawCurtisEmbedding, dict(gamma=0.8, m=24, d=1), x1),
+		("overcomplete_d1", E.OverCompleteHermiteEmbedding, dict(gamma=0.4, m=20, d=1), x1),
+		("lattice_d2", E.LatticeEmbedding, dict(gamma=0.9, m=32, d=2), x2),
+		("matern_laplace_d1", E.MaternEmbedding, dict(gamma=0.5, m=20, d=1, kernel="laplace"), x1),
+		("matern_nu2_d1", E.MaternEmbedding, dict(gamma=0.5, m=20, d=1, kernel="modified_matern", nu=2), x1),
+	]
+	names = []
+	for tag, cls, kw, xx in cases:
+		emb = cls(**kw)
+		out[tag + "_W"] = N(emb.W)
+		out[tag + "_weights"] = N(emb.weights)
+		out[tag + "_m"] = np.array(emb.get_m())
+		out[tag + "_z"] = N(emb.embed(T(xx)))
+		names.append(tag)
+	# the kernel the Hermite features approximate (exact SE for comparison in the tests: Phi Phi^T -> k)
+	emb = E.HermiteEmbedding(gamma=0.7, m=2 * 12 ** 2, d=2, kappa=1.0)
+	Phi = emb.embed(T(x2))
+	out["hermite_d2_gram_m288"] = N(Phi @ Phi.T)
+	out["se_d2_gram"] = N(KernelFunction(kernel_name="squared_exponential", gamma=0.7, d=2).kernel(T(x2), T(x2)))
+	save("Q1_quadrature", x1=x1, x2=x2, x3=x3, **out)
+
+	# ---------------------------------------------------------------- G13: KernelizedFeatures on Hermite features (tutorial: exact GP vs QFF)
+	rng13 = np.random.RandomState(131)
+	d, Ntr, M = 2, 250, 60
+	x = rng13.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(3 * x[:, :1]) * np.cos(2 * x[:, 1:2]) + 0.1 * rng13.normal(size=(Ntr, 1))
+	xtest = rng13.uniform(-1, 1, size=(M, d))
+	emb = E.HermiteEmbedding(gamma=0.5, m=2 * 10 ** 2, d=d, kappa=1.2)
+	KF = KernelizedFeatures(embedding=emb, m=emb.get_m(), s=0.15, lam=1.0, d=d)
+	KF.fit_gp(T(x), T(y))
+	mu, std = KF.mean_std(T(xtest))
+	GP = GaussianProcess(gamma=0.5, s=0.15, kappa=1.2, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(T(x), T(y))
+	mu_gp, std_gp = GP.mean_std(T(xtest))
+	save("G13_hermite_features", x=x, y=y, xtest=xtest, gamma=np.array(0.5), kappa=np.array(1.2), s=np.array(0.15), lam=np.array(1.0), m=np.array(emb.get_m()),
+		 mu=N(mu), std=N(std), mu_exact_gp=N(mu_gp), std_exact_gp=N(std_gp))
+
 	# ---------------------------------------------------------------- B1: beta() and norm() (gauss_procc.py:179-196)
 	rng3 = np.random.RandomState(20241103)
 	x = rng3.uniform(-1, 1, size=(14, 2)); y = np.sin(x.sum(axis=1, keepdims=True)) + 0.05 * rng3.normal(size=(14, 1))

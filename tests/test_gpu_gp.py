@@ -828,3 +828,40 @@ def test_fp32_mode(S):
 	assert rel_err(N(mu).astype(np.float64), mu_o) < 1e-3 and rel_err(N(std).astype(np.float64), std_o) < 1e-3
 	lm_o = O.log_marginal(x32.double().numpy(), y32.double().numpy(), spec, s)[0, 0]
 	assert abs(lml(GP) - lm_o) / abs(lm_o) < 1e-3
+
+
+def test_log_marginal_tracks_changed_hyperparameters(S):
+	"""The reference rebuilds K from the CURRENT self.s / params_dict on every log_marginal call (gauss_procc.py:631-638).
+	The resident factor may only be reused while neither has changed since fit_gp."""
+	n, d = 700, 3
+	x, y, _ = synth(n, d, 4, seed=5)
+	GP = S.GaussianProcess(gamma=1.3, s=0.2, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(x.cuda(), y.cuda())
+	spec = [("squared_exponential", {"gamma": 1.3, "kappa": 1.0}, "-")]
+	v0 = lml(GP)
+	assert abs(v0 - O.log_marginal(x.numpy(), y.numpy(), spec, 0.2)[0, 0]) / abs(v0) < TOL
+	GP.s = 0.35                                            # noise changed after the fit
+	v1 = lml(GP)
+	assert abs(v1 - O.log_marginal(x.numpy(), y.numpy(), spec, 0.35)[0, 0]) / abs(v1) < TOL
+	GP.kernel_object.params_dict['0']['gamma'] = 0.9       # kernel parameter edited in place after the fit
+	spec2 = [("squared_exponential", {"gamma": 0.9, "kappa": 1.0}, "-")]
+	v2 = lml(GP)
+	assert abs(v2 - O.log_marginal(x.numpy(), y.numpy(), spec2, 0.35)[0, 0]) / abs(v2) < TOL
+	GP.fit_gp(x.cuda(), y.cuda())                          # refit: the new factor is current again and is reused
+	L_before = GP._L.data_ptr()
+	assert abs(lml(GP) - v2) / abs(v2) < 1e-12 and GP._L.data_ptr() == L_before
+
+
+def test_failed_refit_leaves_the_object_unfitted(S):
+	"""fit_gp clears `fitted` before factoring; a refit that is not positive definite must not leave fitted=True behind."""
+	n, d = 300, 2
+	x, y, xt = synth(n, d, 16, seed=6)
+	GP = S.GaussianProcess(gamma=1.0, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(x.cuda(), y.cuda())
+	assert GP.fitted
+	GP.kernel_object.params_dict['0']['kappa'] = -1.0       # k(x,x) + s^2 I is no longer positive definite
+	with pytest.raises(torch.linalg.LinAlgError):
+		GP.fit_gp(x.cuda(), y.cuda())
+	assert GP.fitted is False and GP._L is None
+	mu, sd = GP.mean_std(xt.cuda())                        # prior branch, no crash inside the C ABI
+	assert float(mu.abs().max()) == 0.0

@@ -121,15 +121,96 @@ def test_undersized_workspace_is_refused(L):
 	winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device="cuda:0")
 	info = torch.zeros(1, dtype=torch.int32, device="cuda:0")
 	small = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, 256)), dtype=torch.uint8, device="cuda:0")
-	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(small), small.numel(), 512, L.ptr(info), L.stream_ptr()) == -20
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(small), small.numel(), 512, 0, L.ptr(info), L.stream_ptr()) == -20
 	assert b"workspace" in lib.stpy_last_error_string()
-	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(small), small.numel(), 256, L.ptr(info), L.stream_ptr()) == 0
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(small), small.numel(), 256, 0, L.ptr(info), L.stream_ptr()) == 0
 	x = dev(np.random.RandomState(0).normal(size=(300, 5)))
 	il = dev(np.ones(5))
 	out = torch.empty((300, 300), dtype=torch.float64, device="cuda:0")
 	tiny = torch.empty(64, dtype=torch.uint8, device="cuda:0")
 	assert lib.stpy_gram(0, L.F64, L.ptr(x), 300, 5, L.ptr(x), 300, 5, 5, None, L.ptr(il), 1.0, 0.0, 0.0, 0, 0, L.ptr(out), 300, L.ptr(tiny), 64, L.stream_ptr()) == -20
 	torch.cuda.synchronize()
+
+
+def test_undersized_winv_is_refused(L):
+	"""every entry point that takes the inverse diagonal blocks takes their element count and refuses a short array (-21)"""
+	lib = L.load()
+	n = 1024
+	Kd = dev(np.eye(n) * 2.0)
+	need = int(lib.stpy_potrf_winv_elems(n))
+	assert need == (n // 128) * 128 * 128
+	short = torch.empty(need - 128 * 128, dtype=torch.float64, device="cuda:0")
+	winv = torch.empty(need, dtype=torch.float64, device="cuda:0")
+	info = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+	work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, 0)), dtype=torch.uint8, device="cuda:0")
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(short), short.numel(), L.ptr(work), work.numel(), 0, 0, L.ptr(info), L.stream_ptr()) == -21
+	assert b"winv" in lib.stpy_last_error_string()
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), 0, 0, L.ptr(info), L.stream_ptr()) == 0
+	B = dev(np.ones((256, n)))
+	assert lib.stpy_trsm_right_lt(L.F64, 256, n, L.ptr(Kd), n, L.ptr(winv), short.numel(), L.ptr(B), n, 0, 0, None, 0, L.stream_ptr()) == -21
+	y, z = dev(np.ones(n)), dev(np.zeros(n))
+	assert lib.stpy_trsv(L.F64, n, L.ptr(Kd), n, L.ptr(winv), short.numel(), L.ptr(y), L.ptr(z), 0, L.stream_ptr()) == -21
+	Kinv = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
+	w2 = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
+	assert lib.stpy_potri(L.F64, n, L.ptr(Kd), n, L.ptr(winv), short.numel(), L.ptr(Kinv), n, L.ptr(w2), w2.numel() * 8, L.stream_ptr()) == -21
+	# unknown flag bits are refused too
+	assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), 0, 64, L.ptr(info), L.stream_ptr()) == -10
+	torch.cuda.synchronize()
+
+
+def test_two_threads_two_streams(L):
+	"""Two host threads factor and solve two different SPD systems concurrently, each on its own HIP stream.  The look-ahead
+	side stream and events are per caller stream, the error string is thread-local and the per-call behaviour is a flag,
+	so the results are identical (bit for bit) to the same calls issued one after the other."""
+	import threading
+	lib = L.load()
+	n, m = 4096, 1024
+	rng = np.random.RandomState(11)
+	mats = []
+	for t in range(2):
+		A = rng.normal(size=(n, 64))
+		K = A @ A.T / 64.0 + (2.0 + t) * np.eye(n)
+		mats.append((K, rng.normal(size=(m, n))))
+
+	def run(K, B, stream, flags):
+		with torch.cuda.stream(stream):
+			Kd, Bd = dev(K), dev(B)
+			winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device="cuda:0")
+			work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, 0)), dtype=torch.uint8, device="cuda:0")
+			info = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+			sp = ctypes.c_void_p(stream.cuda_stream)
+			for _ in range(3):          # several calls per thread: the two threads' launches interleave
+				Kd.copy_(dev(K))
+				Bd.copy_(dev(B))
+				assert lib.stpy_potrf(L.F64, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), 0, flags, L.ptr(info), sp) == 0
+				assert lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, 0, flags, None, 0, sp) == 0
+			stream.synchronize()
+			assert int(info.item()) == 0
+			return torch.tril(Kd).cpu().numpy(), Bd.cpu().numpy()
+
+	torch.cuda.synchronize()
+	s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+	serial = [run(mats[0][0], mats[0][1], s0, 0), run(mats[1][0], mats[1][1], s1, L.FLAG_BESIDE_UPDATE)]
+	out = [None, None]
+	errs = []
+
+	def worker(i, stream, flags):
+		try:
+			torch.cuda.set_device(0)
+			out[i] = run(mats[i][0], mats[i][1], stream, flags)
+		except Exception as exc:          # noqa: BLE001
+			errs.append(exc)
+	th = [threading.Thread(target=worker, args=(0, s0, 0)), threading.Thread(target=worker, args=(1, s1, L.FLAG_BESIDE_UPDATE))]
+	for t in th:
+		t.start()
+	for t in th:
+		t.join()
+	assert not errs, errs
+	for i in range(2):
+		assert np.array_equal(out[i][0], serial[i][0]) and np.array_equal(out[i][1], serial[i][1])
+		Lf = np.linalg.cholesky(mats[i][0])
+		assert rel_err(out[i][0], Lf) < 1e-12
+		assert rel_err(out[i][1], np.linalg.solve(Lf, mats[i][1].T).T) < 1e-11
 
 
 @pytest.mark.parametrize("m,n,k,nbd,pr,pc,myr,myc,i0,j0", [
@@ -337,7 +418,7 @@ def run_potrf(L, K, nb=0, dtype=torch.float64):
 	winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=dtype, device="cuda:0")
 	work = torch.empty((int(lib.stpy_potrf_workspace_bytes(code, n, nb)),), dtype=torch.uint8, device="cuda:0")
 	info = torch.full((1,), -5, dtype=torch.int32, device="cuda:0")
-	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), nb, L.ptr(info), L.stream_ptr()), "potrf")
+	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
 	return Kd, winv, int(info.item())
 
 
@@ -380,7 +461,7 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 	lib = L.load()
 	B = rng.normal(size=(m, n))
 	Bd = dev(B)
-	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, nb, None, 0, L.stream_ptr()), "trsm")
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, nb, 0, None, 0, L.stream_ptr()), "trsm")
 	Xref = sla.solve_triangular(Lref, B.T, lower=True).T
 	assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 	# the same solve with the K-pass workspace
@@ -392,24 +473,24 @@ def test_trsm_trsv_predict_logdet(L, n, m, nb):
 		assert (wb == 0) == (n <= (nb if nb > 0 else 512))
 		Bw = dev(B)
 		wk = torch.empty(max(wb, 1), dtype=torch.uint8, device="cuda:0")
-		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bw), n, nb, L.ptr(wk), wk.numel() * wk.element_size(), L.stream_ptr()), "trsm")
+		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bw), n, nb, 0, L.ptr(wk), wk.numel() * wk.element_size(), L.stream_ptr()), "trsm")
 		assert rel_err(Bw.cpu().numpy(), Xref) < 1e-11
 		# right-looking sweep and the recursive form (the default from 2048 rows on) with 128-, 256- and 512-column leaves
 		for alg in (1, 3, 4, 5):
 			lib.stpy_tune(5, alg)
 			assert alg == 1 or int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, nb)) == 0
 			Ba = dev(B)
-			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Ba), n, nb, None, 0, L.stream_ptr()), "trsm")
+			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Ba), n, nb, 0, None, 0, L.stream_ptr()), "trsm")
 			assert rel_err(Ba.cpu().numpy(), Xref) < 1e-11, alg
 	finally:
 		lib.stpy_tune(5, 0)
 	y = rng.normal(size=n)
 	yd, zd, ad = dev(y), torch.empty(n, dtype=torch.float64, device="cuda:0"), torch.empty(n, dtype=torch.float64, device="cuda:0")
-	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
+	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
 	zref = sla.solve_triangular(Lref, y, lower=True)
 	assert rel_err(zd.cpu().numpy(), zref) < 1e-11
 	zs = zd.clone()
-	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(zs), L.ptr(ad), 1, L.stream_ptr()), "trsv")
+	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(zs), L.ptr(ad), 1, L.stream_ptr()), "trsv")
 	aref = sla.solve_triangular(Lref.T, zref, lower=False)
 	assert rel_err(ad.cpu().numpy(), aref) < 1e-10
 	kdiag = np.full(m, 5.0 + np.max(np.sum(Xref * Xref, axis=1)))
@@ -435,7 +516,7 @@ def test_potri(L, n, nb):
 	lib = L.load()
 	Kinv = torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda:0")
 	work = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
-	L.check(lib.stpy_potri(L.F64, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Kinv), n, L.ptr(work), work.numel() * work.element_size(), L.stream_ptr()), "potri")
+	L.check(lib.stpy_potri(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Kinv), n, L.ptr(work), work.numel() * work.element_size(), L.stream_ptr()), "potri")
 	out = Kinv.cpu().numpy()
 	ref = np.linalg.inv(K)
 	il = np.tril_indices(n)
@@ -478,9 +559,9 @@ def test_rff(L, n, d, m):
 	out = torch.empty((n, m), dtype=torch.float64, device="cuda:0")
 	scale = np.sqrt(2.0 / m) * np.sqrt(2.5)
 	xd, Wd, bd = dev(x), dev(W), dev(b)          # keep the device buffers alive across the launches
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5)) < 1e-14
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5, b=b).T) < 1e-14
 
 
@@ -493,10 +574,10 @@ def test_rff_transposed(L, dtype, tol):
 	xd, Wd, bd = dev(x, dtype), dev(W, dtype), dev(b, dtype)
 	out = torch.empty((m, n), dtype=dtype, device="cuda:0")
 	scale = np.sqrt(2.0 / m)
-	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x, W, m).T
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
-	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x, W, m, b=b)          # the reference's biased orientation is already (m, n)
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
 
@@ -512,7 +593,7 @@ def test_trsm_many_rows_default_is_recursive(L):
 		assert int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, 0)) == 0
 		B = rng.normal(size=(m, n))
 		Bd = dev(B)
-		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), L.ptr(Bd), n, 0, None, 0, L.stream_ptr()), "trsm")
+		L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, 0, 0, None, 0, L.stream_ptr()), "trsm")
 		Xref = sla.solve_triangular(np.linalg.cholesky(K), B.T, lower=True).T
 		assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 
@@ -530,16 +611,16 @@ def test_rff_f32(L, n, d, m):
 	x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
 	scale = float(np.sqrt(2.0 / m))
 	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x64, W64, m)
 	assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 	refb = O.rff_embed(x64, W64, m, b=b64)            # (m, n) in the reference's biased orientation
 	assert np.abs(out.cpu().numpy() - refb.T).max() < 2e-5 * np.abs(refb).max()
 	outT = torch.empty((m, n), dtype=torch.float32, device="cuda:0")
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
 	assert np.abs(outT.cpu().numpy() - ref.T).max() < 2e-5 * np.abs(ref).max()
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
 	assert np.abs(outT.cpu().numpy() - refb).max() < 2e-5 * np.abs(refb).max()
 
 
@@ -559,7 +640,7 @@ def test_rff_f32_tile_kernel_matches_gemm_epilogue(L):
 			lib.stpy_tune(9, route)
 			for bias in (None, bd):
 				out = torch.full((n, ldo), 7.0, dtype=torch.float32, device="cuda:0")
-				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, scale, L.ptr(out), ldo, 0, L.stream_ptr()), "rff")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), ldo, 0, L.stream_ptr()), "rff")
 				outs[(route, bias is not None)] = out.cpu().numpy()
 	finally:
 		lib.stpy_tune(9, 1)
@@ -587,7 +668,7 @@ def test_rff_f32_streaming_kernel(L):
 			lib.stpy_tune(9, route)
 			for bias in (None, bd):
 				out = torch.full((n, m), 7.0, dtype=torch.float32, device="cuda:0")
-				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
 				outs[(route, bias is not None)] = out.cpu().numpy()
 	finally:
 		lib.stpy_tune(9, 1)
@@ -609,3 +690,31 @@ def test_error_reporting(L):
 	x = dev(np.zeros((2, 2)))
 	rc = lib.stpy_gemm_nt(7, 2, 2, 2, L.ptr(x), 2, L.ptr(x), 2, L.ptr(x), 2, 0, 0, L.stream_ptr())
 	assert rc < 0 and b"dtype" in lib.stpy_last_error_string()
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m,n,ldo,lds", [(300, 300, 300, 300), (257, 130, 136, 132), (5, 3, 7, 3), (1, 1000, 1000, 1000)])
+def test_combine_and_predict_finish(L, dtype, m, n, ldo, lds):
+	"""stpy_combine: out (set | + | *)= src on a strided window, then + diag_add on the diagonal; stpy_predict_finish:
+	mu *= scale, sigma = sqrt(kdiag - scale * sumsq) (the post-all-reduce epilogue of the sharded prediction)."""
+	lib = L.load()
+	rng = np.random.RandomState(m + n)
+	code = L.dtype_code(dtype)
+	npdt = np.float64 if dtype == torch.float64 else np.float32
+	for comb in (L.OUT_SET, L.OUT_ADD, L.OUT_MUL):
+		a, b = rng.normal(size=(m, ldo)).astype(npdt), rng.normal(size=(m, lds)).astype(npdt)
+		ad, bd = dev(a, dtype), dev(b, dtype)
+		L.check(lib.stpy_combine(code, m, n, L.ptr(ad), ldo, L.ptr(bd), lds, comb, 0.25, L.stream_ptr()), "combine")
+		ref = a.copy()
+		w = ref[:, :n]
+		w[...] = b[:, :n] if comb == L.OUT_SET else (w + b[:, :n] if comb == L.OUT_ADD else w * b[:, :n])
+		k = min(m, n)
+		w[np.arange(k), np.arange(k)] += npdt(0.25)
+		assert np.array_equal(ad.cpu().numpy(), ref)          # elementwise: exact, and nothing outside the window is touched
+	assert lib.stpy_combine(code, m, n, L.ptr(ad), n - 1, L.ptr(bd), lds, 0, 0.0, L.stream_ptr()) == -5
+	mu, ss, kd = rng.normal(size=m).astype(npdt), rng.uniform(0, 1, size=m).astype(npdt), rng.uniform(1, 2, size=m).astype(npdt)
+	mud, ssd, kdd = dev(mu, dtype), dev(ss, dtype), dev(kd, dtype)
+	sg = torch.empty(m, dtype=dtype, device="cuda:0")
+	L.check(lib.stpy_predict_finish(code, m, L.ptr(mud), L.ptr(ssd), L.ptr(kdd), 0.5, L.ptr(sg), 0, L.stream_ptr()), "predict_finish")
+	tol = 1e-15 if dtype == torch.float64 else 1e-6
+	assert rel_err(mud.cpu().numpy(), mu * npdt(0.5)) < tol and rel_err(sg.cpu().numpy(), np.sqrt(kd - npdt(0.5) * ss)) < tol

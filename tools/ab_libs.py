@@ -48,9 +48,9 @@ def step(lib, n, d, m, x, xt, y):
 	tw = torch.empty(int(lib.stpy_trsm_workspace_bytes(code, m, n, 0)), dtype=torch.uint8, device=dev)
 	def run():
 		assert lib.stpy_gram(0, code, L.ptr(x), n, d, L.ptr(x), n, d, d, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()) == 0
-		assert lib.stpy_potrf(code, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel(), 0, L.ptr(info), L.stream_ptr()) == 0
+		assert lib.stpy_potrf(code, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), 0, 0, L.ptr(info), L.stream_ptr()) == 0
 		assert lib.stpy_gram(0, code, L.ptr(x), n, d, L.ptr(xt), m, d, d, None, L.ptr(il), 1.0, 0.0, 0.0, 0, 0, L.ptr(X), n, L.ptr(ws2), ws2.numel(), L.stream_ptr()) == 0
-		assert lib.stpy_trsm_right_lt(code, m, n, L.ptr(K), n, L.ptr(winv), L.ptr(X), n, 0, L.ptr(tw) if tw.numel() else None, tw.numel(), L.stream_ptr()) == 0
+		assert lib.stpy_trsm_right_lt(code, m, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(X), n, 0, 0, L.ptr(tw) if tw.numel() else None, tw.numel(), L.stream_ptr()) == 0
 	return run, (K, X)
 
 for n, d, m in ((16384, 8, 4096), (65536, 16, 4096)):

@@ -17,11 +17,11 @@ tw = torch.empty(int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, 0)), dtype=torch
 def gram():
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(x), n, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel() * ws.element_size(), L.stream_ptr()), "gram")
 def potrf():
-	L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), 0, L.ptr(info), L.stream_ptr()), "potrf")
+	L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), 0, 0, L.ptr(info), L.stream_ptr()), "potrf")
 def kstar():
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 16, L.ptr(xt), m, 16, 16, None, L.ptr(il), 1.0, 0.0, 0.0, 0, 0, L.ptr(X), n, L.ptr(ws), ws.numel() * ws.element_size(), L.stream_ptr()), "gram")
 def trsm():
-	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(K), n, L.ptr(winv), L.ptr(X), n, 0, L.ptr(tw), tw.numel() * tw.element_size(), L.stream_ptr()), "trsm")
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(X), n, 0, 0, L.ptr(tw), tw.numel() * tw.element_size(), L.stream_ptr()), "trsm")
 def T(f):
 	torch.cuda.synchronize(); t0 = time.perf_counter(); f(); torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e3
 for rnd in range(2):

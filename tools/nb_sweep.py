@@ -16,7 +16,7 @@ for n in (8192, 16384, 24576):
 		work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), dtype=torch.uint8, device=dev)
 		def f():
 			L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 8, L.ptr(x), n, 8, 8, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()), "gram")
-			L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel(), nb, L.ptr(info), L.stream_ptr()), "potrf")
+			L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
 		f(); torch.cuda.synchronize()
 		ts = []
 		for _ in range(4):

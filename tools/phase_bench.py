@@ -35,7 +35,7 @@ def main():
 	info = torch.zeros(1, dtype=torch.int32, device=dev)
 	def potrf(nb):
 		gp.kernel_object._kernel_into(gp._xd, gp._xd, K, None, 0.01, True)
-		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), nb, L.ptr(info), L.stream_ptr()), "potrf")
+		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
 	for nb in (0, 256, 512, 1024):
 		print("  gram+potrf nb=%-4d %.2f ms" % (nb, t(lambda: potrf(nb))))
 	X = torch.empty(m, n, dtype=torch.float64, device=dev)
@@ -45,7 +45,7 @@ def main():
 		wk = torch.empty(max(wb, 1), dtype=torch.uint8, device=dev)
 		def trsm():
 			gp.kernel_object._kernel_into(gp._xd, xt, X)
-			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), L.ptr(X), X.stride(0), nb, L.ptr(wk) if ww else None, wk.numel() if ww else 0, L.stream_ptr()), "trsm")
+			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), gp._winv.numel(), L.ptr(X), X.stride(0), nb, 0, L.ptr(wk) if ww else None, wk.numel() if ww else 0, L.stream_ptr()), "trsm")
 		print("  K* + trsm nb=%-4d work=%d %.2f ms" % (nb, ww, t(trsm)))
 
 if __name__ == "__main__":

@@ -16,6 +16,6 @@ info = torch.zeros(1, dtype=torch.int32, device=dev)
 ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, 8)), dtype=torch.uint8, device=dev)
 for _ in range(3):
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 8, L.ptr(x), n, 8, 8, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel() * ws.element_size(), L.stream_ptr()), "gram")
-	L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), nb, L.ptr(info), L.stream_ptr()), "potrf")
+	L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
 	torch.cuda.synchronize()
 print("info", int(info.item()))

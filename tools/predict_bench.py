@@ -32,7 +32,7 @@ def main():
 			for it in range(3):
 				gp.kernel_object._kernel_into(gp._xd, xt, X)
 				torch.cuda.synchronize(); t0 = time.perf_counter()
-				L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), L.ptr(X), X.stride(0), nb,
+				L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), gp._winv.numel(), L.ptr(X), X.stride(0), nb, 0,
 											   L.ptr(wk) if use_work else None, wk.numel() if use_work else 0, L.stream_ptr()), "trsm")
 				torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 			t = min(ts)

@@ -52,7 +52,7 @@ def bench_potrf(n, nb):
 	print("gram lower n=%d: tile kernel %.3f ms %.2f TB/s | MFMA+epilogue %.3f ms  %.2f TB/s" % (n, t0 * 1e3, n * n * 8 * 0.5 / t0 / 1e12, t * 1e3, n * n * 8 * 0.5 / t / 1e12), flush=True)
 	def f():
 		gram()
-		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel() * work.element_size(), nb, L.ptr(info), L.stream_ptr()), "potrf")
+		L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
 	t2, _ = timeit(f, reps=2)
 	tp = t2 - t
 	print("potrf n=%d nb=%d: %.3f ms  %.1f TF/s  info=%d" % (n, nb, tp * 1e3, n ** 3 / 3.0 / tp / 1e12, int(info.item())), flush=True)

@@ -14,7 +14,7 @@ for exp in [int(v) for v in sys.argv[1:]] or (0, 1, 2, 4, 3, 5, 6, 7, 0):
 	ts = []
 	for it in range(4):
 		torch.cuda.synchronize(); t0 = time.perf_counter()
-		L.check(lib.stpy_rff_embed(L.F32, L.ptr(x), n, d, d, L.ptr(W), d, m, None, math.sqrt(2.0 / m), L.ptr(out), m, 0, L.stream_ptr()), "rff")
+		L.check(lib.stpy_rff_embed(L.F32, L.ptr(x), n, d, d, L.ptr(W), d, m, None, None, math.sqrt(2.0 / m), L.ptr(out), m, 0, L.stream_ptr()), "rff")
 		torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 	print("exp %d (%s%s%s): %.2f ms" % (exp, "no-store " if exp & 1 else "", "no-mfma " if exp & 2 else "", "no-load " if exp & 4 else "", min(ts) * 1e3), flush=True)
 lib.stpy_tune(1, 0)

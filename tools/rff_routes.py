@@ -13,7 +13,7 @@ for rnd in range(4):
 	for route in (1, 2, 0):
 		lib.stpy_tune(9, route)
 		torch.cuda.synchronize(); t0 = time.perf_counter()
-		L.check(lib.stpy_rff_embed(L.F32, L.ptr(x), n, d, d, L.ptr(W), d, m, None, math.sqrt(2.0 / m), L.ptr(out), m, 0, L.stream_ptr()), "rff")
+		L.check(lib.stpy_rff_embed(L.F32, L.ptr(x), n, d, d, L.ptr(W), d, m, None, None, math.sqrt(2.0 / m), L.ptr(out), m, 0, L.stream_ptr()), "rff")
 		torch.cuda.synchronize(); res.setdefault(route, []).append(time.perf_counter() - t0)
 lib.stpy_tune(9, 1)
 for route, name in ((1, "streaming"), (2, "tile"), (0, "gemm epilogue")):

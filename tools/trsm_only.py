@@ -17,5 +17,5 @@ wk = torch.empty(int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, 0)), dtype=torch
 for it in range(3):
 	gp.kernel_object._kernel_into(gp._xd, xt, X)
 	torch.cuda.synchronize()
-	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), L.ptr(X), X.stride(0), 0, L.ptr(wk), wk.numel() * wk.element_size(), L.stream_ptr()), "trsm")
+	L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), gp._winv.numel(), L.ptr(X), X.stride(0), 0, 0, L.ptr(wk), wk.numel() * wk.element_size(), L.stream_ptr()), "trsm")
 	torch.cuda.synchronize()

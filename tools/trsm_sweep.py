@@ -18,7 +18,7 @@ def factor(n, dtype):
 	winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=dtype, device=dev)
 	work = torch.empty(int(lib.stpy_potrf_workspace_bytes(code, n, 0)), dtype=torch.uint8, device=dev)
 	info = torch.zeros(1, dtype=torch.int32, device=dev)
-	L.check(lib.stpy_potrf(code, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel(), 0, L.ptr(info), L.stream_ptr()), "potrf")
+	L.check(lib.stpy_potrf(code, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), 0, 0, L.ptr(info), L.stream_ptr()), "potrf")
 	assert int(info.item()) == 0
 	return K, winv
 
@@ -37,7 +37,7 @@ for dtype in (torch.float64, torch.float32):
 					lib.stpy_tune(5, v)
 					tw = torch.empty(int(lib.stpy_trsm_workspace_bytes(code, m, n, 0)), dtype=torch.uint8, device=dev)
 					X.copy_(B); torch.cuda.synchronize(); t0 = time.perf_counter()
-					L.check(lib.stpy_trsm_right_lt(code, m, n, L.ptr(K), n, L.ptr(winv), L.ptr(X), n, 0, L.ptr(tw) if tw.numel() else None, tw.numel(), L.stream_ptr()), "trsm")
+					L.check(lib.stpy_trsm_right_lt(code, m, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(X), n, 0, 0, L.ptr(tw) if tw.numel() else None, tw.numel(), L.stream_ptr()), "trsm")
 					torch.cuda.synchronize(); res.setdefault(v, []).append(time.perf_counter() - t0)
 					if rnd == 0:
 						outs[v] = X[:64].clone()

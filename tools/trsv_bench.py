@@ -16,7 +16,7 @@ for n in (16384, 65536):
 		for _ in range(4):
 			src = yv.clone()
 			torch.cuda.synchronize(); t0 = time.perf_counter()
-			L.check(lib.stpy_trsv(L.F64, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), L.ptr(src), L.ptr(z), tr, L.stream_ptr()), "trsv")
+			L.check(lib.stpy_trsv(L.F64, n, L.ptr(gp._L), gp._L.stride(0), L.ptr(gp._winv), gp._winv.numel(), L.ptr(src), L.ptr(z), tr, L.stream_ptr()), "trsv")
 			torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 		print("n=%d trsv trans=%d: %.2f ms (%.1f us per 128-block step)" % (n, tr, min(ts) * 1e3, min(ts) * 1e6 / (n / 128)), flush=True)
 	del gp, x, y

@@ -42,7 +42,7 @@ def main():
 		info = torch.zeros(1, dtype=torch.int32, device=dev)
 		def ours():
 			gram(1)
-			L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), L.ptr(work), work.numel(), 0, L.ptr(info), L.stream_ptr()), "potrf")
+			L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), 0, 0, L.ptr(info), L.stream_ptr()), "potrf")
 		tg, _ = timed(lambda: gram(1))
 		to, _ = timed(ours, reps=3)
 		to -= tg
@@ -50,7 +50,7 @@ def main():
 		tw = torch.empty(int(lib.stpy_trsm_workspace_bytes(L.F64, m, n, 0)), dtype=torch.uint8, device=dev)
 		def ours_trsm():
 			X.copy_(B)
-			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(K), n, L.ptr(winv), L.ptr(X), n, 0, L.ptr(tw), tw.numel(), L.stream_ptr()), "trsm")
+			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(X), n, 0, 0, L.ptr(tw), tw.numel(), L.stream_ptr()), "trsm")
 		tc, _ = timed(lambda: X.copy_(B))
 		ts, _ = timed(ours_trsm, reps=3)
 		ts -= tc
