@@ -235,7 +235,9 @@ void stpy_profile_enable(int enable);
  * 2 scalar diagonal-block kernel (0) · 3 / 4 pass depth and workgroup target of the left-looking block solve ·
  * 5 block-solve algorithm (0 auto, 1 right-looking, 2 left-looking) · 6 direct-to-VGPR GEMM from this many tiles (1; 0 never) ·
  * 7 diagonal block first below this order (8192) · 8 one-volley K = 128 kernel up to this many 64-tiles (768; 0 never) ·
- * 9 fp32 RFF route (1: streaming kernel for large d = 64 shapes + tile kernel; 2: tile kernel only; 0: GEMM epilogue) */
+ * 9 fp32 RFF route (1: streaming kernel for large d = 64 shapes + tile kernel; 2: tile kernel only; 0: GEMM epilogue) ·
+ * 10 look-ahead panels run in "beside" mode (kernels that fit into what two update workgroups leave over on a CU) while the
+ *    trailing update has at least this many rows (0: always) · 11 the four-wave / 64-VGPR diagonal-block kernel in that mode (0) */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */
 int stpy_tune_get(int key);

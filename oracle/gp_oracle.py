@@ -327,6 +327,20 @@ def rff_sample_W(gamma, m, d, rng_state=None):
 	return np.random.normal(size=(m, d)) * (1. / gamma)
 
 
+def quadrature_embed(x, W, weights, kappa=1.0, cosine=False):
+	"""
+	embedding.py:450-466 (QuadratureEmbedding.embed and every derived class): with q = W[:, :d] x^T (m/2, n),
+	rows 0..m/2-1 are sqrt(w_j) cos(q_j) and rows m/2..m-1 are sqrt(w_j) sin(q_j) of the SAME nodes; ``cosine``: the
+	cosine rows only.  Returns (n, m) times sqrt(kappa).
+	"""
+	x = np.asarray(x, dtype=np.float64)
+	W = np.asarray(W, dtype=np.float64)
+	sw = np.sqrt(np.asarray(weights, dtype=np.float64)).reshape(-1, 1)
+	q = W[:, 0:x.shape[1]] @ x.T
+	z = sw * np.cos(q) if cosine else np.concatenate([sw * np.cos(q), sw * np.sin(q)])
+	return z.T * np.sqrt(kappa)
+
+
 # --------------------------------------------------------------------------------------------
 # Primal ridge regression on a finite feature map  (stpy/continuous_processes/kernelized_features.py)
 # --------------------------------------------------------------------------------------------

@@ -144,7 +144,7 @@ int stpy_potrf(int dtype, int64_t n, void* A, int64_t lda, void* winv, int64_t w
 	WORK_CHECK("stpy_potrf", work_bytes, stpy_potrf_workspace_bytes(dtype, n, nb));
 	if (flags & ~STPY_FLAG_BESIDE_UPDATE) { set_error("stpy_potrf: unknown flag bits 0x%x", flags); return -10; }
 	hipStream_t st = (hipStream_t)stream;
-	const int gf = (flags & STPY_FLAG_BESIDE_UPDATE) ? GEMM_NO_K128 : 0;
+	const int gf = (flags & STPY_FLAG_BESIDE_UPDATE) ? GEMM_BESIDE : 0;
 	DISPATCH(dtype,
 	         potrf<double>(n, (double*)A, lda, (double*)winv, (double*)work, nb, info_dev, st, gf),
 	         potrf<float>(n, (float*)A, lda, (float*)winv, (float*)work, nb, info_dev, st, gf));
@@ -166,7 +166,7 @@ int stpy_trsm_right_lt(int dtype, int64_t m, int64_t n, const void* L, int64_t l
 	if (!L || !winv || !B) { set_error("stpy_trsm_right_lt: null pointer"); return -4; }
 	WINV_CHECK("stpy_trsm_right_lt", winv_elems, n);
 	if (flags & ~STPY_FLAG_BESIDE_UPDATE) { set_error("stpy_trsm_right_lt: unknown flag bits 0x%x", flags); return -11; }
-	const int gf = (flags & STPY_FLAG_BESIDE_UPDATE) ? GEMM_NO_K128 : 0;
+	const int gf = (flags & STPY_FLAG_BESIDE_UPDATE) ? GEMM_BESIDE : 0;
 	if (work) WORK_CHECK("stpy_trsm_right_lt", work_bytes, stpy_trsm_workspace_bytes(dtype, m, n, nb));
 	if (m < 0 || n <= 0 || ldl < n || ldb < n) { set_error("stpy_trsm_right_lt: bad dimensions"); return -2; }
 	hipStream_t st = (hipStream_t)stream;
@@ -348,6 +348,8 @@ void stpy_tune(int key, int value)
 	if (key == 7) g_potrf_diag_first_below = value;
 	if (key == 8) g_gemm_k128 = value;
 	if (key == 9) g_rff_tile = value;
+	if (key == 10) g_potrf_beside_min = value;
+	if (key == 11) g_potf2_sliver = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
@@ -364,6 +366,8 @@ int stpy_tune_get(int key)
 	case 7: return g_potrf_diag_first_below;
 	case 8: return g_gemm_k128;
 	case 9: return g_rff_tile;
+	case 10: return g_potrf_beside_min;
+	case 11: return g_potf2_sliver;
 	default: return -1;
 	}
 }

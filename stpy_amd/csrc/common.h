@@ -18,7 +18,7 @@ extern int g_gemm_stagger;
 extern int g_gemm_exp;
 extern int g_gemm_dtv, g_gemm_dtv_min_k, g_gemm_k128;
 extern int g_rff_tile;
-extern int g_potf2_scalar;
+extern int g_potf2_scalar, g_potf2_sliver;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
@@ -32,7 +32,8 @@ struct LookAhead {
 int lookahead_acquire(hipStream_t caller, LookAhead** out);
 
 // per-call behaviour flags of stpy_potrf / stpy_trsm_right_lt (include/stpy_hip.h: STPY_FLAG_*), passed down to the GEMM launcher
-constexpr int GEMM_NO_K128 = 1;      // = STPY_FLAG_BESIDE_UPDATE: never take the 128 KiB one-volley kernel
+constexpr int GEMM_BESIDE = 1;       // = STPY_FLAG_BESIDE_UPDATE: the launch runs while a trailing update floods the chip -- take the kernels
+                                     // that fit into what two update workgroups leave over on a CU (never the 128 KiB one-volley kernel)
 
 // ---- optional launch profiler (stpy_profile_*): HIP events recorded on the launch stream around
 // ---- every tagged kernel, so bench.py can report the dominant kernel's live average duration.
@@ -85,7 +86,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
             const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr, int ksplit = 1, T* split_work = nullptr, int gflags = 0);
 int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);      // recommended number of K passes for a product with few output tiles
 template <typename T>
-int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st);
+int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st, bool beside = false);
 template <typename T>
 int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info, hipStream_t st, int gflags = 0);
 template <typename T>
@@ -93,7 +94,7 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
 extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking;
-extern int g_potrf_diag_first_below;
+extern int g_potrf_diag_first_below, g_potrf_beside_min;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
 template <typename T>

@@ -24,6 +24,7 @@
 // K tile (two 16-byte LDS reads for f64) and MFMA number s of the tile uses element s of every
 // lane: k-slots {s, 4+s, 8+s, 12+s}.  A and B use the same map, which is all that is required.
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace stpy {
@@ -73,7 +74,10 @@ struct GemmArgs {
 	// split-K (few output tiles, long K): the super-tile range is enumerated ksplit times; pass s
 	// contracts K range [s*kchunk, (s+1)*kchunk) into the partial result at C + s*split_stride
 	int ksplit, kchunk; int64_t split_stride;
+	unsigned long long* dbg;      // diagnostic builds (-DSTPY_STAMPS) only: in-kernel time stamps, never read by any kernel
 };
+unsigned long long* g_gemm_dbg = nullptr;
+extern "C" void stpy_debug_set_stamp_buffer(void* p) { g_gemm_dbg = (unsigned long long*)p; }
 
 // Random-Fourier-feature epilogue: scale * cos(q + b) or scale * sin(q).  fp64: libm-accurate.
 // fp32: the phase is reduced to revolutions in fp32 (q/2pi minus its nearest integer, exact for
@@ -859,6 +863,151 @@ void gemm_nt_k128_kernel(GemmArgs<double> p)
 			}
 }
 
+// ------------------------------------------------------------------------------------------
+// "Sliver" variant of the same panel-chain products (n = 128 columns, K a multiple of 16, fp64), for launches that are
+// enqueued WHILE a trailing update floods the chip (look-ahead panels, STPY_FLAG_BESIDE_UPDATE).  Two update workgroups
+// leave 512 - 2*224 = 64 VGPRs per SIMD lane and 160 - 2*32 = 96 KiB of LDS on every CU.  A workgroup that needs more
+// waits for an update workgroup to exit -- i.e. for the next "round" boundary of the update, 70-270 us per launch in the
+// kernel traces, three launches per 128-column block -- while one that fits into the leftovers is placed at once
+// (tools/sliver_probe.hip: 79 us beside the update = 79 us alone for a 64-VGPR / 80 KiB workgroup; 101-128 us instead of
+// 63 for the 128-VGPR shape).  So: 256 threads capped at 64 VGPRs, 80 KiB of LDS, one workgroup per CU beside the update.
+//   tile 32 rows x 128 columns (the full width: an in-place product C = A W^T is safe), wave tile 16 x 64;
+//   both operands through LDS-DMA (costs no VGPRs) in a ring of four 16-deep K tiles, one barrier per K tile;
+//   every K tile issues its prefetch unconditionally (clamped to the last tile), so the vmcnt bookkeeping is constant.
+// ------------------------------------------------------------------------------------------
+constexpr int SL_TM = 32, SL_TN = 128, SL_BK = 16, SL_NS = 4;
+constexpr int SL_LDS_BYTES = SL_NS * (SL_TM + SL_TN) * SL_BK * 8;          // 80 KiB
+// (dynamic LDS on purpose: with a static 80 KiB array hipcc sees that eight waves per SIMD are out of reach anyway and
+// drops the register cap that amdgpu_waves_per_eu(8, 8) = 64 VGPRs is here to enforce)
+template <bool SUB>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void gemm_nt_sliver_kernel(GemmArgs<double> p)
+{
+	typedef double T;
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	constexpr int SROWS = SL_TM + SL_TN;                         // rows of one stage: 32 of A, 128 of B, 128 bytes each
+	extern __shared__ __attribute__((aligned(16))) unsigned char sliver_smem_raw[];
+	double* const smem = reinterpret_cast<double*>(sliver_smem_raw);
+#ifdef STPY_STAMPS
+	unsigned long long stamp[5];
+	stamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+	// The sliver shares every SIMD with two (older) update waves that issue MFMAs back to back; instruction issue is arbitrated
+	// by priority, then age, so at equal priority it only gets the leftover slots (kernel trace: 105-117 us beside the update
+	// for a launch that takes 15 us alone).  It is the latency-critical party: top priority for its whole life.
+	__builtin_amdgcn_s_setprio(3);
+	const int row0 = blockIdx.x * SL_TM;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
+	const int KT = p.k / SL_BK;
+
+	// ---- LDS-DMA: a stage is 20 pieces of 8 rows (1 KiB); wave w moves piece w (A rows 8w..) and pieces w + 4i (B rows
+	// ---- 8w + 32(i-1)..), i = 1..4.  Piece parity = w & 1 for all five, so one swizzle term serves them; addresses are a
+	// ---- uniform 64-bit base (SGPRs) plus one 32-bit lane offset per operand.
+	const int rl = lane >> 3;
+	const int fsrc = (((rl >> 1) & 3) << 1) | (wave & 1);
+	const unsigned alane = ((unsigned)rl * (unsigned)p.lda + (unsigned)(((lane & 7) ^ fsrc) * 2)) * 8u;
+	const unsigned blane = ((unsigned)rl * (unsigned)p.ldb + (unsigned)(((lane & 7) ^ fsrc) * 2)) * 8u;
+	const T* const abase = p.A + (int64_t)(row0 + 8 * wave) * p.lda;
+	const T* const bbase = p.B + (int64_t)(8 * wave) * p.ldb;
+	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
+	auto dma_one = [&](const T* gbase, unsigned voff, unsigned laddr) {
+		unsigned keep;
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(laddr) : "memory");
+	};
+	auto dma_stage = [&](int kt) {                               // K tile kt (clamped) into ring slot kt % NS
+		const int k0 = min(kt, KT - 1) * SL_BK;
+		const unsigned base = lds0 + (unsigned)((kt & (SL_NS - 1)) * SROWS) * 128u;
+		dma_one(abase + k0, alane, base + (unsigned)(8 * wave) * 128u);
+#pragma unroll
+		for (int i = 1; i <= 4; ++i) dma_one(bbase + (int64_t)(32 * (i - 1)) * p.ldb + k0, blane, base + (unsigned)(SL_TM + 8 * wave + 32 * (i - 1)) * 128u);
+	};
+
+	// ---- prologue: three K tiles in flight, the C tile behind them, ONE wait the compiler can see (see gemm_nt_dtv_kernel)
+	dma_stage(0);
+	dma_stage(1);
+	dma_stage(2);
+	// C addressing: register i of a lane is row (lane >> 4) + 4 i of the wave's 16 rows: a uniform base per i (SGPRs) plus ONE
+	// 32-bit lane offset; the four column tiles are immediate offsets
+	v4 acc[4];
+	T* const ctile = p.C + (int64_t)(row0 + wm * 16) * p.ldc + wn * 64;          // uniform
+	// (byte offsets in 32 bits, so that every access is  global_load/store v, v_off, s[base:base+1] offset:imm  and no 64-bit
+	// per-lane address has to stay alive across the K loop -- with 64 VGPRs those went to scratch)
+	const unsigned clane = ((unsigned)g * (unsigned)p.ldc + (unsigned)r16) * 8u;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const char* const ci = (const char*)(ctile + (int64_t)(4 * i) * p.ldc);  // uniform
+#pragma unroll
+		for (int t = 0; t < 4; ++t) acc[t][i] = SUB ? *(const T*)(ci + clane + t * 128) : T(0);
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+	__syncthreads();
+#ifdef STPY_STAMPS
+	stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);
+	const int aoff = (wm * 16 + r16) * SL_BK, boff = (SL_TM + wn * 64 + r16) * SL_BK;
+	for (int kt = 0; kt < KT; ++kt) {
+		if (kt > 0) {
+			// tiles kt+1 and kt+2 (ten pieces of this wave) may still be in flight; tile kt has landed
+			asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+			__syncthreads();                     // ... for every wave, and everybody has finished reading tile kt-1
+		}
+		dma_stage(kt + 3);                       // into the slot tile kt-1 occupied
+		const T* st = smem + (kt & (SL_NS - 1)) * SROWS * SL_BK;
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int off = ((2 * g + h) ^ fsw) * 2;
+			const d2 fa = *(const d2*)(st + aoff + off);
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				const d2 fb = *(const d2*)(st + boff + t * 16 * SL_BK + off);
+#pragma unroll
+				for (int s2 = 0; s2 < 2; ++s2) acc[t] = SUB ? MM::mms(fa[s2], fb[s2], acc[t]) : MM::mma(fa[s2], fb[s2], acc[t]);
+			}
+		}
+	}
+#ifdef STPY_STAMPS
+	stamp[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+	// the clamped prefetches of the last tiles are still landing: drained before the LDS is given back, and every wave has
+	// consumed its A rows before anybody stores (C may alias A)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+#ifdef STPY_STAMPS
+	stamp[3] = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		char* const ci = (char*)(ctile + (int64_t)(4 * i) * p.ldc);
+#pragma unroll
+		for (int t = 0; t < 4; ++t) *(T*)(ci + clane + t * 128) = acc[t][i];
+	}
+	if (p.C2) {
+		T* const c2tile = p.C2 + (int64_t)(row0 + wm * 16) * p.ldc2 + wn * 64;
+		const unsigned c2lane = ((unsigned)g * (unsigned)p.ldc2 + (unsigned)r16) * 8u;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			char* const ci = (char*)(c2tile + (int64_t)(4 * i) * p.ldc2);
+#pragma unroll
+			for (int t = 0; t < 4; ++t) *(T*)(ci + c2lane + t * 128) = acc[t][i];
+		}
+	}
+#ifdef STPY_STAMPS
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	stamp[4] = __builtin_amdgcn_s_memrealtime();
+	if (p.dbg && tid == 0 && blockIdx.x < 512) {
+		unsigned long long* d = p.dbg + (size_t)blockIdx.x * 8;
+		for (int q = 0; q < 5; ++q) d[q] = stamp[q];
+		d[5] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 8 << 6 | 4) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 8);   // HW_ID cu / XCC_ID
+	}
+#endif
+}
+
 // ---- C (=, -=) sum over the split-K partial products (fixed order: the result does not depend on scheduling)
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -986,6 +1135,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		p.kskip = 1;
 	}
 	p.ksplit = 1; p.kchunk = 0; p.split_stride = 0;
+	p.dbg = g_gemm_dbg;
 	if (ksplit > 1) {       // partial products go to the packed workspace [ksplit][m][n]; summed below
 		p.ksplit = ksplit;
 		p.kchunk = (int)kchunk;
@@ -1027,9 +1177,25 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
 	if constexpr (sizeof(T) == 8) {
+		// panel-chain products enqueued beside a trailing update (see gemm_nt_sliver_kernel)
+		if ((gflags & GEMM_BESIDE) && n == SL_TN && (m % SL_TM == 0) && (k % SL_BK == 0) && k >= SL_BK && (mode == 0 || mode == 1) && !lower_only && !bc &&
+		    p.ksplit == 1 && !g_gemm_exp && (lda % 2 == 0) && (ldb % 2 == 0) && lda < (1 << 24) && ldb < (1 << 24) && ldc < ((int64_t)1 << 28) && ldc2 < ((int64_t)1 << 28) &&
+		    (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {
+			static std::atomic<bool> attr_set{false};
+			if (!attr_set.load(std::memory_order_acquire)) {
+				hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_sliver_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES);
+				if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_sliver_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES);
+				if (e != hipSuccess) { set_error("gemm_nt (sliver): hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
+				attr_set.store(true, std::memory_order_release);
+			}
+			const dim3 gs((unsigned)(m / SL_TM));
+			if (mode == 1) hipLaunchKernelGGL((gemm_nt_sliver_kernel<true>), gs, block, SL_LDS_BYTES, st, p);
+			else hipLaunchKernelGGL((gemm_nt_sliver_kernel<false>), gs, block, SL_LDS_BYTES, st, p);
+			return check_launch("gemm_nt (sliver)");
+		}
 		// the panel chain's K = 128 products (see gemm_nt_k128_kernel)
 		const int64_t t64 = ((m + 63) / 64) * (n / 64);
-		if (g_gemm_k128 && !(gflags & GEMM_NO_K128) && k == 128 && (n % 128 == 0) && (mode == 0 || mode == 1) && !lower_only && !bc && p.ksplit == 1 && !g_gemm_exp &&
+		if (g_gemm_k128 && !(gflags & GEMM_BESIDE) && k == 128 && (n % 128 == 0) && (mode == 0 || mode == 1) && !lower_only && !bc && p.ksplit == 1 && !g_gemm_exp &&
 		    t64 <= g_gemm_k128 && (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {
 			const dim3 g64((unsigned)((m + 63) / 64), (unsigned)(n / 128));
 			if (mode == 1) hipLaunchKernelGGL((gemm_nt_k128_kernel<true>), g64, block, 0, st, p);

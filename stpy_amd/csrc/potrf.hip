@@ -22,6 +22,11 @@ namespace stpy {
 // default outer panel width: 1024 halves the read+write passes over the trailing matrix compared
 // with 512 (measured 2 % faster end to end at N = 65 536); the solves keep 512 (see solve.hip)
 int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B runs)
+// stpy_tune key 11 (0 = off, the default): blocks factored beside a trailing update take the 64-VGPR / four-wave form below.
+// Measured (tools/potrf_sweep.py, gpurun_out/potrf_sweep3.log): it is placed at once, as intended, but then RUNS 8x slower
+// beside the real update than alone (730-770 us against 94 us in the kernel trace) and loses to the eight-wave kernel that
+// waits for a slot (N = 16 384 potrf 41.0 ms against 36.7 ms).  Kept switchable for the next experiment, not used.
+int g_potf2_sliver = 0;
 constexpr int PT_THREADS = 512;
 constexpr int SLD = 132;     // LDS row stride in elements: 132 = 4 (mod 32) keeps the (row, k mod 4) lane map conflict-free
 
@@ -406,21 +411,226 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	}
 }
 
+// ------------------------------------------------------------------------------------------
+// "Sliver" form of the same kernel for blocks factored WHILE a trailing update floods the chip (look-ahead panels):
+// 256 threads capped at 64 VGPRs and the same 83 KiB of LDS, i.e. it fits into what two update workgroups leave over on
+// a CU (512 - 2*224 VGPRs, 160 - 2*32 KiB) and is placed at once, where the eight-wave / 128-VGPR form above has to wait
+// for an update workgroup to exit -- 200-270 us per block in the kernel traces (tools/sliver_probe.hip: 79 us beside the
+// update = 79 us alone).  Same algorithm; what changes with four waves and a quarter of the registers:
+//   * the block is loaded in four batches of 16 values per thread;
+//   * sub-block rows / trailing pairs are dealt over 4 (3) waves instead of 8 (7);
+//   * the triangular inverse handles two block columns per wave, and finished blocks W_kj are re-read from the output
+//     array (L2-hot, written by the same wave) instead of being kept in registers.
+// ------------------------------------------------------------------------------------------
+constexpr int PS_THREADS = 256, PS_WAVES = 4;
 template <typename T>
-int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st)
+__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void potf2_trtri_sliver_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
+                               T* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
+{
+	typedef Mfma<T> MM;
+	typedef typename MM::v4 v4;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	T* S = reinterpret_cast<T*>(smem_raw);          // [TRI] packed lower triangle
+	T* WD = S + TRI;                                // [8][16][WLD]
+	T* SC = WD + NSB * SB * WLD;                    // [4 waves][16][WLD] scratch: C/D fragment -> B operand re-layout
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int r16 = lane & 15, g = lane >> 4;
+	// beside two older, MFMA-saturating update waves per SIMD this kernel's serial pivot chain gets only leftover issue slots
+	// at equal priority (kernel trace: 730-770 us beside the update, 94 us alone): top priority for its whole life
+	__builtin_amdgcn_s_setprio(3);
+
+	{
+		// thread t owns column j = t & 127 and the rows i = (t >> 7) + 2 it: one base pointer and a uniform stride; eight loads in
+		// flight per batch (the eight-wave kernel keeps all 32 of a thread in registers, which 64 VGPRs cannot hold)
+		const int j = tid & 127, i0 = tid >> 7;
+		const T* src = A + (int64_t)i0 * lda + j;
+		const int64_t step = 2 * lda;
+		constexpr int NIT = IB * IB / PS_THREADS, BATCH = 8;
+#pragma unroll 1
+		for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+			T v[BATCH];
+#pragma unroll
+			for (int it = 0; it < BATCH; ++it) {
+				const int i = i0 + 2 * (b0 + it);
+				v[it] = (j <= i && i < nbk) ? src[(int64_t)it * step] : ((i == j) ? T(1) : T(0));
+			}
+#pragma unroll
+			for (int it = 0; it < BATCH; ++it) {
+				const int i = i0 + 2 * (b0 + it);
+				if (j <= i) S[tri(i, j)] = v[it];
+			}
+			src += BATCH * step;
+		}
+	}
+	__syncthreads();
+
+	// ---- 16x16 diagonal sub-block (one wave): factor and inverse together, four lanes per row (see the kernel above)
+	auto diag_block = [&](int kb) {
+		const int o = kb * SB;
+		const int q = lane >> 4, i = lane & 15;
+		T a[4], w[4];
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const int col = 4 * q + c;
+			a[c] = (col <= i) ? S[tri(o + i, o + col)] : T(0);
+			w[c] = (col == i) ? T(1) : T(0);
+		}
+		int first_bad = 0;
+		// (the group loop stays rolled: sixteen unrolled pivots hoist so many lane-permute addresses and constants that the
+		// kernel cannot stay within 64 VGPRs; inside a group the column index is a compile-time register index)
+#pragma unroll 1
+		for (int qj = 0; qj < 4; ++qj) {
+#pragma unroll
+			for (int cj = 0; cj < 4; ++cj) {
+				const int j = 4 * qj + cj;
+				T d = bcast(a[cj], 16 * qj + j);
+				const bool bad = !(d > T(0)) || !(d < T(1e300));
+				first_bad = (bad && first_bad == 0) ? j + 1 : first_bad;
+				d = bad ? T(1) : d;
+				T rl = (T)__builtin_amdgcn_rsq(d);
+				rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+				rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+				const T l = d * rl;
+				const T colv = (i == j) ? l : a[cj] * rl;
+				a[cj] = (q == qj && i >= j) ? colv : a[cj];
+				const T mi = __shfl(colv, 16 * qj + i, 64);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int k = 4 * q + c;
+					const T lk = __shfl(colv, 16 * qj + 4 * q + c, 64);
+					const T wj = __shfl(w[c], 16 * q + j, 64);
+					const T na = a[c] - mi * lk;
+					a[c] = (k > j && i >= k) ? na : a[c];
+					const T ws = wj * rl;
+					const T nw = w[c] - mi * ws;
+					w[c] = (i == j) ? ws : ((i > j) ? nw : w[c]);
+				}
+			}
+		}
+		if (first_bad != 0 && lane == 0) atomicCAS(info, 0, block_row0 + o + first_bad);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const int col = 4 * q + c;
+			if (col <= i) S[tri(o + i, o + col)] = a[c];
+			WD[(kb * SB + i) * WLD + col] = (col <= i) ? w[c] : T(0);
+		}
+	};
+	auto trail_pair = [&](int kb, int bi, int bj) {
+		const int o = kb * SB;
+		const bool diag = bi == bj;
+		v4 acc;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int rr = MM::crow(lane, q);
+			acc[q] = (!diag || r16 <= rr) ? S[tri(bi * SB + rr, bj * SB + r16)] : T(0);
+		}
+#pragma unroll
+		for (int s4 = 0; s4 < 4; ++s4)
+			acc = MM::mma(-S[tri(bi * SB + r16, o + 4 * s4 + g)], S[tri(bj * SB + r16, o + 4 * s4 + g)], acc);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const int rr = MM::crow(lane, q);
+			if (!diag || r16 <= rr) S[tri(bi * SB + rr, bj * SB + r16)] = acc[q];
+		}
+	};
+
+	// (one call site for the diagonal sub-block: the loop starts one step early, with only wave 0's first sub-block in it)
+#pragma unroll 1
+	for (int kb = -1; kb < NSB; ++kb) {
+		const int o = kb * SB;
+		if (kb >= 0) {
+			__syncthreads();
+			for (int bi = kb + 1 + wave; bi < NSB; bi += PS_WAVES) {           // panel below: X_bi = A_bi * WD^T
+				v4 acc = v4{0, 0, 0, 0};
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4)
+					acc = MM::mma(S[tri(bi * SB + r16, o + 4 * s4 + g)], WD[(kb * SB + r16) * WLD + 4 * s4 + g], acc);
+#pragma unroll
+				for (int q = 0; q < 4; ++q) S[tri(bi * SB + MM::crow(lane, q), o + r16)] = acc[q];
+			}
+			__syncthreads();
+		}
+		if (kb + 1 < NSB) {
+			if (kb >= 0) {
+				for (int bi = kb + 1 + wave; bi < NSB; bi += PS_WAVES) trail_pair(kb, bi, kb + 1);      // column kb+1 first
+				__syncthreads();
+			}
+			if (wave == 0) diag_block(kb + 1);
+			else if (kb >= 0) {
+				const int nrem = NSB - 2 - kb, npair = nrem * (nrem + 1) / 2;
+				for (int pidx = wave - 1; pidx < npair; pidx += PS_WAVES - 1) {
+					int a = 0, rem = pidx;
+					while (rem > a) { rem -= a + 1; ++a; }
+					trail_pair(kb, kb + 2 + a, kb + 2 + rem);
+				}
+			}
+		}
+	}
+	__syncthreads();
+
+	for (int idx = tid; idx < IB * IB; idx += PS_THREADS) {
+		const int i = idx >> 7, j = idx & 127;
+		const T v = (j <= i) ? S[tri(i, j)] : T(0);
+		if (i < nbk && j < nbk) {
+			if (j <= i) A[(int64_t)i * lda + j] = v;
+			if (P2) P2[(int64_t)i * ldp2 + j] = v;
+		}
+		const int bi = i >> 4, bj = j >> 4;
+		if (bj > bi) W[idx] = T(0);
+		else if (bj == bi) W[idx] = WD[(bi * SB + (i & 15)) * WLD + (j & 15)];
+	}
+
+	// ---- triangular inverse: wave w owns block columns w and w + 4; W_ij = -WD_i * sum_{k=j}^{i-1} L_ik W_kj, the finished
+	// ---- blocks of the column re-read from W (stores drained and ordered before the loads of the next step)
+	T* sc = SC + wave * SB * WLD;
+	for (int j = wave; j < NSB - 1; j += PS_WAVES) {
+		for (int i = j + 1; i < NSB; ++i) {
+			v4 t = v4{0, 0, 0, 0};
+			for (int k = j; k < i; ++k) {
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4) {
+					const T a = S[tri(i * SB + r16, k * SB + 4 * s4 + g)];
+					const T b = (k == j) ? WD[(j * SB + 4 * s4 + g) * WLD + r16] : W[(k * SB + 4 * s4 + g) * IB + j * SB + r16];
+					t = MM::mma(a, b, t);
+				}
+			}
+			v4 w = v4{0, 0, 0, 0};
+#pragma unroll
+			for (int q = 0; q < 4; ++q) sc[MM::crow(lane, q) * WLD + r16] = t[q];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int s4 = 0; s4 < 4; ++s4) w = MM::mma(-WD[(i * SB + r16) * WLD + 4 * s4 + g], sc[(4 * s4 + g) * WLD + r16], w);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			__builtin_amdgcn_wave_barrier();          // (sc is rewritten by the next step only after every lane has read it)
+		}
+	}
+}
+
+template <typename T>
+int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st, bool beside)
 {
 	const size_t lds_old = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
 	const size_t lds_new = (size_t)(TRI + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
+	const size_t lds_sliver = (size_t)(TRI + NSB * SB * WLD + PS_WAVES * SB * WLD) * sizeof(T);
 	static std::atomic<bool> attr_set[2];          // (idempotent: two threads racing here both set the same attribute values)
 	const int which = sizeof(T) == 8 ? 0 : 1;
 	if (!attr_set[which].load(std::memory_order_acquire)) {
 		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_sliver_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliver);
 		if (e != hipSuccess) { set_error("potf2: hipFuncSetAttribute(%zu B LDS) failed: %s", lds_new, hipGetErrorString(e)); return -1000 - (int)e; }
 		attr_set[which].store(true, std::memory_order_release);
 	}
 	if (g_potf2_scalar)
 		hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(PT_THREADS), lds_old, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	else if (beside && g_potf2_sliver)
+		hipLaunchKernelGGL((potf2_trtri_sliver_kernel<T>), dim3(1), dim3(PS_THREADS), lds_sliver, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	else
 		hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	return check_launch("potf2_trtri");
@@ -432,6 +642,13 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 // Two host threads on two streams get two sets; calls on one stream are enqueued in program order and the events
 // of a set are only ever recorded / awaited by calls on that stream, so re-use across calls needs no further care.
 int g_potrf_diag_first_below = 8192;     // stpy_tune key 7
+// stpy_tune key 10: a look-ahead panel whose trailing update still has at least this many rows runs BESIDE that update and
+// takes the "sliver" GEMM for its panel products (gemm.hip: fits into what two update workgroups leave over on a CU, so it
+// is placed at once) instead of the tile kernels, which wait for an update workgroup to exit, or the 128 KiB one-volley
+// kernel, which needs a CU without any update workgroup.  tools/potrf_sweep.py, one process: with the threshold at 0 (every
+// look-ahead panel) potrf takes 10.2 / 36.7 / 194.4 / 1396 ms at N = 8192 / 16 384 / 32 768 / 65 536 against
+// 11.6 / 40.4 / 206.5 / 1411 ms without the beside mode.
+int g_potrf_beside_min = 0;
 namespace {
 struct LaKey { int device; hipStream_t stream; bool operator<(const LaKey& o) const { return device != o.device ? device < o.device : stream < o.stream; } };
 std::mutex g_la_mutex;
@@ -480,7 +697,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 		}
 		{
 			ProfScope ps(TAG_POTF2, (double)cb * cb * cb / 3.0, st);
-			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st);
+			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st, (gflags & GEMM_BESIDE) != 0);
 		}
 		if (rc) return rc;
 		if (c == k && first_diag && hipEventRecord(first_diag, st) != hipSuccess) { set_error("potrf: event record failed"); return -1003; }
@@ -540,7 +757,8 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		// 83 KiB of LDS -- waits ~200 us for a CU slot once the update's workgroups have flooded the chip (kernel trace,
 		// tools/potrf_only.py).  Below the threshold the update therefore starts only after that kernel has run.
 		const bool diag_first = (n - r) <= g_potrf_diag_first_below;
-		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, gflags, diag_first ? la->trail_done : nullptr);
+		const int pflags = gflags | ((n - r - nkb) >= g_potrf_beside_min ? GEMM_BESIDE : 0);
+		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, pflags, diag_first ? la->trail_done : nullptr);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(la->panel_done, side));
 		if (diag_first) HIPCHK(hipStreamWaitEvent(st, la->trail_done, 0));
@@ -561,8 +779,8 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 	return 0;
 }
 
-template int potf2_trtri<double>(double*, int64_t, int, double*, double*, int64_t, int32_t*, int, hipStream_t);
-template int potf2_trtri<float>(float*, int64_t, int, float*, float*, int64_t, int32_t*, int, hipStream_t);
+template int potf2_trtri<double>(double*, int64_t, int, double*, double*, int64_t, int32_t*, int, hipStream_t, bool);
+template int potf2_trtri<float>(float*, int64_t, int, float*, float*, int64_t, int32_t*, int, hipStream_t, bool);
 template int potrf<double>(int64_t, double*, int64_t, double*, double*, int, int32_t*, hipStream_t, int);
 template int potrf<float>(int64_t, float*, int64_t, float*, float*, int, int32_t*, hipStream_t, int);
 

@@ -23,12 +23,14 @@ fit (right-looking Cholesky, one block column K per step)
 
 predict  (X = K* L^-T, rows = test points, column blocks distributed like L's and replicated down
 each process column)  left-looking, so only M x NB blocks move, never L:
-  X_K = (K*_K - sum_{J<K} X_J L_KJ^T) L_KK^-T :  every rank of process row K%P_r forms the partial
-  sum over ITS local block columns J < K with one GEMM (the operands are contiguous in local
-  storage), the partials are summed onto the diagonal owner (reduce along the process row), the
-  owner finishes the block and broadcasts it down its process column.  mu = X z and
-  sigma^2 = kdiag - rowsum(X o X) are all-reduced partial sums; z = L^-1 y is the same solve with
-  a single right-hand side.
+  X_K = (K*_K - sum_{J<K} X_J L_KJ^T) L_KK^-T :  every rank of process row K%P_r forms the (negative)
+  partial sum over ITS local block columns J < K (the operands are contiguous in local storage), the
+  partials are summed onto the diagonal owner (reduce along the process row), the owner adds K*_K,
+  finishes the block and broadcasts it down its process column.  One block of look-ahead: the part of
+  block K+1's partial sum that does not involve X_K (all J <= K-1) is formed on the side stream while
+  block K's reduce / solve / broadcast chain runs; only the single J = K term (one NB-deep product)
+  sits between two chains.  mu = X z and sigma^2 = kdiag - rowsum(X o X) are all-reduced partial sums
+  finished by ``stpy_predict_finish``; z = L^-1 y is the same solve with a single right-hand side.
 
 All arithmetic goes through a ``LocalOps`` object.  The product backend is ``HipLocalOps`` (the C
 ABI of libstpy_hip; raises without a GPU).  Tests inject a CPU backend from ``tests/`` to exercise
@@ -38,11 +40,15 @@ Look-ahead: one block column.  After panel K is in place the local update of blo
 first; panel K+1 (diagonal factor, panel solve and all three broadcasts) is then issued on a
 high-priority side stream while the main stream applies panel K to the remaining columns.
 
-Round-1 status: exercised on gloo with 2 and 4 CPU ranks and with 1/2/4 ranks sharing one MI355X
-(host-staged collectives); the RCCL path itself has only been read, not run -- the authoring loop
-has a single GPU.  At world size 1 this code path costs 1.91 s for the N=65536 bench step against
-1.81 s for the single-GPU class (tools/dist_bench.py).
+Status: exercised on gloo with 2 ... 8 CPU ranks (CPU stand-in for the tile arithmetic, against the oracle) and
+with 1 / 2 / 4 ranks sharing one MI355X (real HIP kernels, collectives staged through pinned host memory,
+against the oracle and the single-GPU class).  The RCCL transport between GPUs has only run at world size 1
+(process group, high-priority sub-communicators, both streams): the authoring loop has a single GPU and RCCL
+refuses two ranks on one device -- ``DistributedGaussianProcess`` therefore warns once when it is constructed
+on the nccl backend with more than one rank.  DESIGN.md section (f) holds the per-step cost model a measured
+1 / 2 / 4 / 8-GPU curve is to be judged against.
 """
+import warnings
 import ctypes
 import math
 
@@ -75,6 +81,7 @@ class HipLocalOps:
 		self.code = _lib.dtype_code(dtype)
 		self.nb = nb
 		self.flags = 0
+		self._skwork = {}
 
 	def empty(self, *shape):
 		return torch.empty(shape, dtype=self.dtype, device=self.device)
@@ -93,9 +100,23 @@ class HipLocalOps:
 	def to_device(self, t):
 		return _lib.to_device(t, self.dtype)
 
-	def gram(self, kernel_object, xa, xb, out, kwargs=None):
-		"""out[j, i] = k(xb_j, xa_i); out may be a strided 2-D view."""
+	def gram(self, kernel_object, xa, xb, out, kwargs=None, add=False):
+		"""out[j, i] (+)= k(xb_j, xa_i); out may be a strided 2-D view.  ``add``: the value is added to what ``out`` holds."""
+		if add:
+			items = kernel_object._resolve(dict(kwargs) if kwargs else {})
+			if len(items) == 1:
+				kernel_object._run_items([dict(items[0], op="+")], xa, xb, out, first_is_set=False)
+				return
+			tmp = torch.empty_like(out)
+			kernel_object._run_items(items, xa, xb, tmp)
+			self.add_into(out, tmp)
+			return
 		kernel_object._kernel_into(xa, xb, out, kwargs)
+
+	def add_into(self, out, src):
+		"""out += src on (strided) 2-D views."""
+		_lib.check(self.lib.stpy_combine(self.code, out.shape[0], out.shape[1], _lib.ptr(out), out.stride(0), _lib.ptr(src), src.stride(0),
+										 _lib.OUT_ADD, 0.0, _lib.stream_ptr()), "stpy_combine")
 
 	def kdiag(self, kernel_object, xt):
 		out = self.empty(xt.shape[0])
@@ -128,7 +149,11 @@ class HipLocalOps:
 		if bc is None:
 			passes = int(self.lib.stpy_gemm_nt_splitk_passes(m, n, k))
 			if passes > 1:        # few output tiles, long K (partial sums of the distributed solve)
-				work = self.empty(passes * m * n)
+				# one workspace per stream, grown on demand and kept: no allocation inside the per-block loop
+				key = torch.cuda.current_stream().cuda_stream
+				work = self._skwork.get(key)
+				if work is None or work.numel() < passes * m * n:
+					work = self._skwork[key] = self.empty(passes * m * n)
 				_lib.check(self.lib.stpy_gemm_nt_splitk(self.code, m, n, k, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(C), C.stride(0),
 														mode, passes, _lib.ptr(work), work.numel() * work.element_size(), _lib.stream_ptr()), "stpy_gemm_nt_splitk")
 				return
@@ -152,9 +177,9 @@ class HipLocalOps:
 										 _lib.stream_ptr()), "stpy_predict")
 		return s1, s2
 
-	def predict_finish(self, mu, sumsq, kdiag, scale, clamp):
+	def predict_finish(self, mu, sumsq, kdiag, scale, clamp, want_sigma=True):
 		"""mu *= scale (in place); sigma = sqrt(kdiag - scale * sumsq): the epilogue after the all-reduce of the partial sums."""
-		sigma = self.empty(mu.shape[0])
+		sigma = self.empty(mu.shape[0]) if want_sigma else None
 		_lib.check(self.lib.stpy_predict_finish(self.code, mu.shape[0], _lib.ptr(mu), _lib.ptr(sumsq), _lib.ptr(kdiag), float(scale), _lib.ptr(sigma),
 												1 if clamp else 0, _lib.stream_ptr()), "stpy_predict_finish")
 		return mu, sigma
@@ -166,16 +191,25 @@ class HipLocalOps:
 		return out2[0]
 
 
+class _Factor:
+	"""The distributed factor of one (x, hyper-parameter) pair: this rank's local blocks of L, the inverse diagonal
+	blocks the solves reuse, and z = L^-1 y in the column distribution."""
+	__slots__ = ("n", "nblk", "nr", "nc", "Aloc", "winv", "zloc", "xd", "kwargs")
+
+
 class DistributedGaussianProcess:
-	"""``GaussianProcess`` on a P_r x P_c process grid: same constructor, ``fit_gp`` / ``mean_std`` /
-	``log_marginal`` (default hyper-parameters only), results replicated on every rank."""
+	"""``GaussianProcess`` on a P_r x P_c process grid: same constructor arguments for the path, ``add_data_point`` /
+	``fit`` / ``fit_gp`` / ``mean_std`` (``full=True``, ``max_size`` chunking) / ``mean_var`` / ``log_marginal(kernel, X,
+	weight)`` with the kwargs-override protocol; results replicated on every rank.  With one rank nothing is distributed:
+	the object then simply holds a single-GPU ``GaussianProcess`` (``force_path=True`` keeps the block-cyclic code path,
+	which is how its own overhead is measured)."""
 
 	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", nu=1.5, kernel=None, d=1,
-				 grid=None, nb_dist=1024, ops=None, group=None):
+				 grid=None, nb_dist=1024, ops=None, group=None, force_path=False):
 		self.s = s
 		self.d = d
 		self.kernel_object = kernel if kernel is not None else KernelFunction(kernel_name=kernel_name, gamma=gamma, nu=nu, kappa=kappa, d=d)
-		self.ops = ops if ops is not None else HipLocalOps()
+		self.kernel = self.kernel_object.kernel
 		if not dist.is_initialized():
 			raise RuntimeError("DistributedGaussianProcess needs torch.distributed to be initialised (one process per GPU)")
 		self.world = dist.get_world_size()
@@ -187,7 +221,25 @@ class DistributedGaussianProcess:
 			raise ValueError("nb_dist must be a multiple of %d" % IB)
 		self.NB = nb_dist
 		self.nb = 0
+		self.fitted = False
+		self.clamp_variance = False
+		self.max_size = 10000               # gauss_procc.py:55: prediction chunk
+		self.x = self.y = None
+		self.n = 0
+		self._f = None
+		self.stats = {"bcast_bytes": 0, "reduce_bytes": 0, "collectives": 0}
+		# one rank and nothing injected: there is nothing to distribute -- the single-GPU estimator IS the product path
+		self._single = None
+		if self.world == 1 and ops is None and not force_path:
+			from ..continuous_processes.gauss_procc import GaussianProcess
+			self._single = GaussianProcess(s=s, kernel=self.kernel_object, d=d)
+			return
+		self.ops = ops if ops is not None else HipLocalOps()
 		self.myr, self.myc = self.rank // self.Pc, self.rank % self.Pc      # row-major rank -> (row, col)
+		if dist.get_backend() == "nccl" and self.world > 1:
+			warnings.warn("DistributedGaussianProcess: the RCCL transport between GPUs has not been exercised by this build's tests "
+						  "(schedule verified on gloo and on one GPU with staged collectives) -- compare against the single-GPU "
+						  "class on a small problem before relying on it", RuntimeWarning, stacklevel=2)
 		# sub-communicators: every rank creates every group, in the same order
 		# (RCCL: communication kernels go to high-priority streams, i.e. hardware queues of their own, so a
 		# panel broadcast is never queued behind the trailing update it is meant to overlap)
@@ -208,9 +260,6 @@ class DistributedGaussianProcess:
 				raise
 			# (raised identically on every rank before any communicator exists, so the retry stays collective)
 			self.row_groups, self.col_groups = make_groups({})
-		self.fitted = False
-		self.clamp_variance = False
-		self.max_size = 10000
 
 	# ------------------------------------------------------------------ index arithmetic
 	def _rank_of(self, r, c):
@@ -224,74 +273,175 @@ class DistributedGaussianProcess:
 		"""number of local blocks (along one axis) whose global index is < K"""
 		return 0 if K <= my else (K - my + P - 1) // P
 
-	# collectives: RCCL on device tensors; under gloo (debug / single-GPU rehearsal with several
-	# ranks sharing one card) device tensors are staged through the host
+	# collectives: RCCL on device tensors.  Under gloo (debug / single-GPU rehearsal with several ranks sharing one
+	# card) device tensors are staged through PINNED host memory with an event on the issuing stream: only that
+	# stream is waited for, so the ordering between the main and the side stream is exercised as on RCCL.
 	def _staged(self, t):
 		return t.is_cuda and dist.get_backend() == "gloo"
+
+	def _to_host(self, t):
+		h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+		h.copy_(t, non_blocking=True)
+		ev = torch.cuda.Event()
+		ev.record(torch.cuda.current_stream())
+		ev.synchronize()
+		return h
+
+	def _from_host(self, t, h):
+		t.copy_(h, non_blocking=True)
+		self._pinned_keep.append(h)          # pinned source of an asynchronous copy: kept until the end of the fit / predict call
+
+	_pinned_keep = []
+
+	def _count(self, t, kind):
+		self.stats[kind] += t.numel() * t.element_size()
+		self.stats["collectives"] += 1
 
 	def _bcast(self, t, src, group, size):
 		if size <= 1:
 			return
+		self._count(t, "bcast_bytes")
 		if self._staged(t):
-			h = t.cpu()
+			h = self._to_host(t)
 			dist.broadcast(h, src=src, group=group)
-			t.copy_(h)
+			if dist.get_rank() != src:
+				self._from_host(t, h)
 		else:
 			dist.broadcast(t, src=src, group=group)
 
-	def _reduce_sum(self, t, dst, group):
+	def _reduce_sum(self, t, dst, group, size):
+		if size <= 1:
+			return
+		self._count(t, "reduce_bytes")
 		if self._staged(t):
-			h = t.cpu()
+			h = self._to_host(t)
 			dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
-			t.copy_(h)
+			if dist.get_rank() == dst:
+				self._from_host(t, h)
 		else:
 			dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
 
 	def _allreduce(self, t, op):
+		if self.world <= 1:
+			return
+		self._count(t, "reduce_bytes")
 		if self._staged(t):
-			h = t.cpu()
+			h = self._to_host(t)
 			dist.all_reduce(h, op=op)
-			t.copy_(h)
+			self._from_host(t, h)
 		else:
 			dist.all_reduce(t, op=op)
 
+	def _streams(self, on_gpu, bulk=False):
+		"""(main, second stream, two events).  The factorisation's panel look-ahead runs on a HIGH-priority side stream (its
+		small kernels must get CU slots among the trailing update's workgroups); the solve's look-ahead is the bulk of the
+		work and runs on a normal-priority stream beside the latency-bound chain on the caller's stream.  ONE stream of
+		each kind per object -- the caching allocator keeps a pool per stream, so a fresh stream per fit would turn every
+		panel buffer of a re-fit into a hipMalloc / hipFree with its device sync."""
+		if not on_gpu:
+			return None, None, None, None
+		if getattr(self, "_side", None) is None:
+			self._side = torch.cuda.Stream(priority=-1)
+			self._bulk = torch.cuda.Stream()
+			self._ev = [torch.cuda.Event() for _ in range(4)]
+		if bulk:
+			return torch.cuda.current_stream(), self._bulk, self._ev[2], self._ev[3]
+		return torch.cuda.current_stream(), self._side, self._ev[0], self._ev[1]
+
+	# ------------------------------------------------------------------ small API mirrors (gauss_procc.py:100-134)
+	def add_data_point(self, x, y, Sigma=None):
+		"""gauss_procc.py:100-111: concatenate and refit from scratch (every rank holds x, y)."""
+		if Sigma is not None:
+			raise NotImplementedError("a general noise matrix is not provided on the distributed path")
+		if self.x is not None:
+			x = torch.cat((self.x, x), dim=0)
+			y = torch.cat((self.y, y), dim=0)
+		self.fit_gp(x, y)
+
+	add_data = add_data_point
+
+	def fit(self, x=None, y=None):
+		if x is not None:
+			self.fit_gp(x, y)
+		else:
+			self.fit_gp(self.x, self.y)
+
+	def lcb(self, xtest):
+		mu, s = self.mean_std(xtest)
+		return mu - 2 * s
+
+	def ucb(self, xtest):
+		mu, s = self.mean_std(xtest)
+		return mu + 2 * s
+
+	@property
+	def A(self):
+		"""K^-1 y is not assembled on the distributed path (prediction needs only z = L^-1 y)."""
+		if self._single is not None:
+			return self._single.A
+		raise NotImplementedError("alpha = K^-1 y is not assembled on the distributed path")
+
 	# ------------------------------------------------------------------ fit
-	def fit_gp(self, x, y):
-		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
-		xd = ops.to_device(x)
-		yd = ops.to_device(y).reshape(-1)
-		n = xd.shape[0]
-		self.n = n
+	def fit_gp(self, x, y, Sigma=None, iterative=False, extrapoint=False):
+		if Sigma is not None:
+			raise NotImplementedError("a general noise matrix is not provided on the distributed path")
 		self.x, self.y = x, y
-		self._xd = xd
+		self.n, self.d = x.shape[0], x.shape[1]
+		if self._single is not None:
+			self._single.fit_gp(x, y)
+			self.fitted = True
+			return None
+		self.fitted = False
+		self._f = None                      # release the previous factor before allocating the next one
+		xd = self.ops.to_device(x)
+		yd = self.ops.to_device(y).reshape(-1)
+		self._f = self._factorize(xd, yd, None)
+		self._factor_key = self._hyper_key()
+		self.fitted = True
+		return None
+
+	def _hyper_key(self):
+		from ..continuous_processes.gauss_procc import GaussianProcess
+		return GaussianProcess._hyper_key(self, self.kernel_object)
+
+	def _factorize(self, xd, yd, kwargs):
+		"""Gram fill + block-cyclic Cholesky + z = L^-1 y for the kernel parameters in ``kwargs`` (None: the stored ones)."""
+		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
+		n = xd.shape[0]
+		f = _Factor()
+		f.n, f.xd, f.kwargs = n, xd, kwargs
 		nblk = (n + NB - 1) // NB
-		self.nblk = nblk
+		f.nblk = nblk
 		nr = (nblk - myr + Pr - 1) // Pr if nblk > myr else 0         # local block rows / cols
 		nc = (nblk - myc + Pc - 1) // Pc if nblk > myc else 0
-		self.nr, self.nc = nr, nc
+		f.nr, f.nc = nr, nc
+		del self._pinned_keep[:]
 
-		# ---- local Gram fill: one launch over (local row points) x (local col points)
+		# ---- local Gram fill, lower blocks only: local block row i (global I) needs the local block columns j with
+		# ---- global J = j*Pc + myc <= I -- a staircase, one launch per local block row (nothing above the diagonal is
+		# ---- ever read: the trailing update skips those tiles and the panels start at the diagonal)
 		def global_index(nloc, my, P):
 			idx = (torch.arange(nloc * NB, device=xd.device) // NB * P + my) * NB + torch.arange(nloc * NB, device=xd.device) % NB
 			return idx
 		gr = global_index(nr, myr, Pr)
 		gc = global_index(nc, myc, Pc)
-		self._gc = gc
-		self._Aloc = self._zloc = None          # release the previous factor before allocating the next one
-		self._winv = {}
-		self.fitted = False
 		Aloc = ops.empty(max(nr * NB, 1), max(nc * NB, 1))
 		if nr > 0 and nc > 0:
 			xr = xd[gr.clamp(max=n - 1)].contiguous()
 			xc = xd[gc.clamp(max=n - 1)].contiguous()
-			ops.gram(self.kernel_object, xc, xr, Aloc)
+			s2 = float(self.s) ** 2
+			for i in range(nr):
+				I = i * Pr + myr
+				jn = self._count_local_below(I + 1, myc, Pc)            # local block columns with J <= I
+				if jn == 0:
+					continue
+				ops.gram(self.kernel_object, xc[:jn * NB], xr[i * NB:(i + 1) * NB], Aloc[i * NB:(i + 1) * NB, :jn * NB], kwargs)
 			# padding (global index >= n): identity block; noise s^2 on the global diagonal
 			# (the last local index is host arithmetic: ((nloc-1)*P + my)*NB + NB-1 -- no device read-back)
 			if ((nr - 1) * Pr + myr + 1) * NB > n:
 				Aloc[gr >= n, :] = 0
 			if ((nc - 1) * Pc + myc + 1) * NB > n:
 				Aloc[:, gc >= n] = 0
-			s2 = float(self.s) ** 2
 			for i in range(nr):
 				I = i * Pr + myr
 				if I % Pc == myc:
@@ -299,8 +449,8 @@ class DistributedGaussianProcess:
 					dblk = Aloc[i * NB:(i + 1) * NB, j * NB:(j + 1) * NB].diagonal()
 					gdiag = I * NB + torch.arange(NB, device=xd.device)
 					dblk.add_(torch.where(gdiag < n, torch.full_like(dblk, s2), torch.ones_like(dblk)))
-		self._Aloc = Aloc
-		self._winv = {}
+		f.Aloc = Aloc
+		f.winv = {}
 		bad = [torch.zeros((1,), dtype=torch.int32, device=xd.device)]
 
 		# persistent double buffers for the panel operands (allocated once on the caller's stream, so the
@@ -331,7 +481,7 @@ class DistributedGaussianProcess:
 				self._bcast(dpack, self._rank_of(kr, kc), self.col_groups[kc], Pr)
 				Lkk = dpack[:NB * NB].reshape(NB, NB)
 				wkk = dpack[NB * NB:]
-				self._winv[K] = (Lkk, wkk)
+				f.winv[K] = (Lkk, wkk)
 				if rows_below > 0:
 					panel = Aloc[i0 * NB:, lkc * NB:(lkc + 1) * NB]
 					ops.trsm_right_lt(panel, Lkk, wkk)
@@ -366,15 +516,7 @@ class DistributedGaussianProcess:
 		# in the same program order on every rank.  On CPU tensors (tests) there are no streams and the
 		# same statements simply run in order.
 		on_gpu = xd.is_cuda
-		main = torch.cuda.current_stream() if on_gpu else None
-		# (ONE side stream per object: the caching allocator keeps a pool per stream, so a fresh stream per
-		# fit would turn every panel buffer of a re-fit into a hipMalloc / hipFree with its device sync)
-		if on_gpu and getattr(self, "_side", None) is None:
-			self._side = torch.cuda.Stream(priority=-1)
-			self._ev_col, self._ev_panel = torch.cuda.Event(), torch.cuda.Event()
-		side = self._side if on_gpu else None
-		ev_col = self._ev_col if on_gpu else None
-		ev_panel = self._ev_panel if on_gpu else None
+		main, side, ev_col, ev_panel = self._streams(on_gpu)
 
 		cur = panel_step(0, 0)
 		for K in range(nblk):
@@ -413,82 +555,168 @@ class DistributedGaussianProcess:
 		# z = L^-1 y through the same left-looking solve with one right-hand side
 		ypad = ops.zeros(1, nblk * NB)
 		ypad[0, :n] = yd
-		self._zloc = self._solve_rows(ypad, None)
-		self.fitted = True
-		return None
-
-	fit = fit_gp
+		f.zloc = self._solve_rows(f, ypad, None)
+		del self._pinned_keep[:]
+		return f
 
 	# ------------------------------------------------------------------ X = B L^-T, left-looking, column blocks distributed
-	def _solve_rows(self, rhs_full, xtest):
+	def _solve_rows(self, f, rhs_full, xtest):
 		"""
 		rhs rows against L.  Either ``rhs_full`` (m x Npad, replicated; used for y) or ``xtest``
 		(m x d): then block K of the right-hand side, k(x_K, xtest), is formed by the diagonal owner.
 		Returns this rank's column blocks of X: (m, nc*NB).
+
+		Per block K, on process row K % P_r:  S = - sum_{local J < K} X_J L_KJ^T  (accumulated by the subtracting GEMM on
+		a zeroed buffer), reduce onto the diagonal owner, owner:  X_K = (S + rhs_K) L_KK^-T, broadcast down its process
+		column.  Look-ahead: the terms J <= K-1 of block K+1's sum are formed on the side stream while block K's reduce /
+		solve / broadcast chain runs; only the J = K term is added between the chains.  S lives in two preallocated slots.
 		"""
 		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
-		Aloc, n = self._Aloc, self.n
+		Aloc, n, nblk = f.Aloc, f.n, f.nblk
 		m = rhs_full.shape[0] if rhs_full is not None else xtest.shape[0]
-		Xloc = ops.zeros(m, max(self.nc * NB, 1))
-		for K in range(self.nblk):
+		Xloc = ops.zeros(m, max(f.nc * NB, 1))
+		on_gpu = Xloc.is_cuda
+		main, side, ev_a, ev_b = self._streams(on_gpu, bulk=True)
+		S = [ops.empty(m, NB), ops.empty(m, NB)]
+		XKbuf = [ops.empty(m, NB), ops.empty(m, NB)]          # two slots: block K's broadcast may still be in flight when K+1 is formed
+
+		def partial(K, slot, j_lo, j_hi, first):
+			"""S[slot] (-)= X[:, local blocks j_lo..j_hi) L_K,.^T on the current stream (process row K % Pr only)."""
+			if first:
+				S[slot].zero_()
+			if j_hi > j_lo:
+				lkr = K // Pr
+				ops.gemm_nt(Xloc[:, j_lo * NB:j_hi * NB], Aloc[lkr * NB:(lkr + 1) * NB, j_lo * NB:j_hi * NB], S[slot], 1)
+
+		# prologue: block 0 has no predecessors
+		if myr == 0 % Pr:
+			partial(0, 0, 0, 0, True)
+		for K in range(nblk):
 			kr, kc, lkr, lkc = K % Pr, K % Pc, K // Pr, K // Pc
+			slot = K % 2
+			# look-ahead for block K+1 (terms J <= K-1) on the second stream, behind everything `main` has issued up to the
+			# end of step K-1: it reads Xloc blocks < K only (final by then) and writes the OTHER S slot
+			if K + 1 < nblk and myr == (K + 1) % Pr:
+				jn = self._count_local_below(K, myc, Pc)             # local blocks with J <= K-1
+				if on_gpu:
+					ev_a.record(main)
+					with torch.cuda.stream(side):
+						side.wait_event(ev_a)
+						partial(K + 1, (K + 1) % 2, 0, jn, True)
+						ev_b.record(side)
+				else:
+					partial(K + 1, (K + 1) % 2, 0, jn, True)
 			if myr == kr:
-				jc = self._count_local_below(K, myc, Pc)
-				S = ops.zeros(m, NB)
-				if jc > 0:
-					ops.gemm_nt(Xloc[:, :jc * NB], Aloc[lkr * NB:(lkr + 1) * NB, :jc * NB], S, 0)
-				if Pc > 1:
-					self._reduce_sum(S, self._rank_of(kr, kc), self.row_groups[kr])
+				# the one term the look-ahead could not cover: J = K-1 (if this rank holds that block column)
+				if K >= 1 and (K - 1) % Pc == myc:
+					jl = (K - 1) // Pc
+					partial(K, slot, jl, jl + 1, False)
+				self._reduce_sum(S[slot], self._rank_of(kr, kc), self.row_groups[kr], Pc)
 			if myc == kc:
-				XK = ops.empty(m, NB)
+				XK = XKbuf[slot]
 				if myr == kr:
 					if rhs_full is not None:
-						XK.copy_(rhs_full[:, K * NB:(K + 1) * NB])
+						ops.add_into(S[slot], rhs_full[:, K * NB:(K + 1) * NB])
 					else:
 						gk = (K * NB + torch.arange(NB, device=Xloc.device))
-						xk = self._xd[gk.clamp(max=n - 1)].contiguous()
-						ops.gram(self.kernel_object, xk, xtest, XK)          # XK[t, i] = k(xtest_t, x_{K,i})
+						xk = f.xd[gk.clamp(max=n - 1)].contiguous()
 						if (K + 1) * NB > n:
+							# padded columns (global index >= n) carry no kernel value: form the block apart and blank them
+							ops.gram(self.kernel_object, xk, xtest, XK, f.kwargs)
 							XK[:, gk >= n] = 0
-					XK.sub_(S)
-					Lkk, wkk = self._winv[K]
-					ops.trsm_right_lt(XK, Lkk, wkk)
+							ops.add_into(S[slot], XK)
+						else:
+							ops.gram(self.kernel_object, xk, xtest, S[slot], f.kwargs, add=True)      # S += k(xtest, x_K)
+					Lkk, wkk = f.winv[K]
+					ops.trsm_right_lt(S[slot], Lkk, wkk)
+					XK.copy_(S[slot])
 				self._bcast(XK, self._rank_of(kr, kc), self.col_groups[kc], Pr)
 				Xloc[:, lkc * NB:(lkc + 1) * NB] = XK
+			if on_gpu and K + 1 < nblk and myr == (K + 1) % Pr:
+				main.wait_event(ev_b)                                # S[(K+1) % 2] holds the look-ahead part
 		return Xloc
 
 	# ------------------------------------------------------------------ predict
 	def mean_std(self, xtest, full=False, reuse=False):
-		if full:
-			raise NotImplementedError("full covariance is not provided on the distributed path")
+		"""gauss_procc.py:310-334: chunks of ``max_size`` test points against the resident factor."""
+		if self._single is not None:
+			self._single.max_size, self._single.clamp_variance = self.max_size, self.clamp_variance
+			return self._single.mean_std(xtest, full=full, reuse=reuse)
 		if not self.fitted:
 			raise RuntimeError("fit_gp first")
-		ops = self.ops
-		xt = ops.to_device(xtest)
-		Xloc = self._solve_rows(None, xt)
-		red = ops.empty(2, xt.shape[0])
-		ops.row_sums(Xloc[:, :self.nc * self.NB], self._zloc.reshape(-1), out=red)
-		self._allreduce(red, dist.ReduceOp.SUM)
-		kd = ops.kdiag(self.kernel_object, xt)
-		# every process row holds a replica of its columns: scale = 1 / P_r; mu in place, sigma = sqrt(kd - scale * sumsq)
-		mu, sigma = ops.predict_finish(red[0], red[1], kd, 1.0 / self.Pr, self.clamp_variance)
-		return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(sigma.reshape(-1, 1), xtest))
+		m = xtest.shape[0]
+		if m < self.max_size or full:
+			return self._mean_std_sub(xtest, full)
+		mus, sds = [], []
+		for i0 in range(0, m, self.max_size):
+			mu, sd = self._mean_std_sub(xtest[i0:i0 + self.max_size], False)
+			mus.append(mu)
+			sds.append(sd)
+		return torch.cat(mus), torch.cat(sds)
 
 	mean_var = mean_std
 
+	def _mean_std_sub(self, xtest, full):
+		ops, f = self.ops, self._f
+		xt = ops.to_device(xtest)
+		m = xt.shape[0]
+		Xloc = self._solve_rows(f, None, xt)
+		Xl = Xloc[:, :f.nc * self.NB]
+		red = ops.empty(2, m)
+		ops.row_sums(Xl, f.zloc.reshape(-1), out=red)
+		self._allreduce(red, dist.ReduceOp.SUM)
+		# every process row holds a replica of its columns: scale = 1 / P_r
+		if not full:
+			kd = ops.kdiag(self.kernel_object, xt)
+			mu, sigma = ops.predict_finish(red[0], red[1], kd, 1.0 / self.Pr, self.clamp_variance)
+			del self._pinned_keep[:]
+			return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(sigma.reshape(-1, 1), xtest))
+		# full covariance K** - X X^T (gauss_procc.py:396-399): rank (0, 0) starts from K**, every rank of process row 0
+		# subtracts the product over ITS columns of X, the others contribute zeros; one all-reduce assembles the sum
+		cov = ops.zeros(m, m)
+		if self.myr == 0 and self.myc == 0:
+			ops.gram(self.kernel_object, xt, xt, cov)
+		if self.myr == 0 and f.nc > 0:
+			ops.gemm_nt(Xl, Xl, cov, 1)
+		self._allreduce(cov, dist.ReduceOp.SUM)
+		mu, _ = ops.predict_finish(red[0], None, None, 1.0 / self.Pr, False, want_sigma=False)
+		del self._pinned_keep[:]
+		return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(cov, xtest))
+
+	def mean(self, xtest):
+		return self.mean_std(xtest)[0]
+
 	def log_marginal(self, kernel=None, X=None, weight=1.0):
-		"""1/2 z^T z + 1/2 * weight * 2 sum log L_ii for the fitted hyper-parameters (estimator.py:32-40)."""
-		if X:
-			raise NotImplementedError("hyper-parameter overrides are not provided on the distributed path")
+		"""gauss_procc.py:497-504 -> :631-638 (== estimator.py:32-40): 1/2 y^T K^-1 y + 1/2 * weight * log det K, shape (1, 1).
+		``X``: per-item parameter overrides in the kwargs protocol of kernels.py:138-157 -- the matrix is then refilled and
+		refactored with them (as the reference does on every call); with X empty, ``kernel`` the fitted kernel object and
+		unchanged hyper-parameters the resident factor is reused."""
+		kernel = self.kernel_object if kernel is None else kernel
+		if self._single is not None:
+			return self._single.log_marginal(kernel, X if X else {}, weight)
 		ops = self.ops
+		reuse = self.fitted and not X and kernel is self.kernel_object and getattr(self, "_factor_key", None) == self._hyper_key()
+		if reuse:
+			f = self._f
+		else:
+			if self.x is None:
+				raise AttributeError("log_marginal needs data: call fit_gp first")
+			saved = self.kernel_object
+			self.kernel_object = kernel
+			try:
+				f = self._factorize(ops.to_device(self.x), ops.to_device(self.y).reshape(-1), dict(X) if X else None)
+			finally:
+				self.kernel_object = saved
 		acc = ops.zeros(2)
-		for K in range(self.nblk):
+		for K in range(f.nblk):
 			if K % self.Pr == self.myr and K % self.Pc == self.myc:
-				Lkk, _ = self._winv[K]
+				Lkk, _ = f.winv[K]
 				acc[0] += ops.logdet(Lkk)
-		if self.myr == 0 and self.nc > 0:
-			z = self._zloc[:, :self.nc * self.NB]
+		if self.myr == 0 and f.nc > 0:
+			z = f.zloc[:, :f.nc * self.NB]
 			acc[1] = ops.row_sums(z, z.reshape(-1))[1][0]
 		self._allreduce(acc, dist.ReduceOp.SUM)
-		val = 0.5 * acc[1] + 0.5 * float(weight) * 2.0 * acc[0]
+		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
+		val = 0.5 * acc[1] + 0.5 * w * 2.0 * acc[0]
+		del self._pinned_keep[:]
 		return _lib.like_input(val.reshape(1, 1), self.x)

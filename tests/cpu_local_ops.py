@@ -45,8 +45,15 @@ class CpuLocalOps:
 			out = k if it['op'] == "-" else (out + k if it['op'] == "+" else out * k)
 		return out
 
-	def gram(self, kernel_object, xa, xb, out, kwargs=None):
-		out.copy_(torch.from_numpy(self._eval(kernel_object, xa.numpy(), xb.numpy(), kwargs)))
+	def gram(self, kernel_object, xa, xb, out, kwargs=None, add=False):
+		k = torch.from_numpy(self._eval(kernel_object, xa.numpy(), xb.numpy(), kwargs))
+		out.copy_(out + k if add else k)
+
+	def add_into(self, out, src):
+		out.add_(src)
+
+	def beside_update(self, on):
+		pass
 
 	def kdiag(self, kernel_object, xt):
 		x = xt.numpy()
@@ -104,8 +111,10 @@ class CpuLocalOps:
 		out[1] = (X * X).sum(dim=1)
 		return out[0], out[1]
 
-	def predict_finish(self, mu, sumsq, kdiag, scale, clamp):
+	def predict_finish(self, mu, sumsq, kdiag, scale, clamp, want_sigma=True):
 		mu *= scale
+		if not want_sigma:
+			return mu, None
 		var = kdiag - scale * sumsq
 		if clamp:
 			var = var.clamp(min=0)

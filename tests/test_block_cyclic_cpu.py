@@ -44,8 +44,18 @@ def _worker(rank, world, port, grid, n, d, m, nb_dist, kernel_name, nu, q):
 		gp.fit_gp(torch.from_numpy(x), torch.from_numpy(y))
 		mu, std = gp.mean_std(torch.from_numpy(xt))
 		lml = gp.log_marginal()
+		# the wider estimator surface: full covariance, chunked prediction, kwargs overrides, add_data_point
+		mu_f, cov = gp.mean_std(torch.from_numpy(xt[:11]), full=True)
+		gp.max_size = 16
+		mu_c, std_c = gp.mean_std(torch.from_numpy(xt))
+		gp.max_size = 10000
+		lml_o = gp.log_marginal(gp.kernel_object, {'0': {'gamma': torch.tensor(0.9, dtype=torch.float64)}}, 0.5)
+		lml_again = gp.log_marginal(gp.kernel_object, {}, 1.0)          # stored parameters untouched by the override
+		gp.add_data_point(torch.from_numpy(xt[:5]), torch.from_numpy(np.cos(xt[:5].sum(axis=1, keepdims=True))))
+		mu_a, std_a = gp.mean_std(torch.from_numpy(xt[5:]))
 		if rank == 0:
-			q.put((mu.numpy(), std.numpy(), lml.numpy()))
+			q.put((mu.numpy(), std.numpy(), lml.numpy(), mu_f.numpy(), cov.numpy(), mu_c.numpy(), std_c.numpy(), lml_o.numpy(), lml_again.numpy(),
+				   mu_a.numpy(), std_a.numpy(), dict(gp.stats)))
 		# every rank must hold the same replicated result
 		ref = mu.clone()
 		dist.broadcast(ref, src=0)
@@ -74,8 +84,10 @@ def test_block_cyclic_matches_oracle(world, grid, n, nb_dist, kernel_name, nu):
 		p.start()
 	for p in procs:
 		p.join(timeout=300)
+		if p.is_alive():          # a hung rank must not stay behind
+			p.terminate()
 	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-	mu, std, lml = q.get()
+	mu, std, lml, mu_f, cov, mu_c, std_c, lml_ov, lml_again, mu_a, std_a, stats = q.get()
 	x, y, xt = _data(n, d, m)
 	params = {"gamma": 1.3, "kappa": 1.1}
 	if kernel_name == "matern":
@@ -86,8 +98,73 @@ def test_block_cyclic_matches_oracle(world, grid, n, nb_dist, kernel_name, nu):
 	lml_o = O.log_marginal(x, y, spec, 0.2)
 	assert rel_err(mu, mu_o) < 1e-10 and rel_err(std, std_o) < 1e-10
 	assert abs(lml[0, 0] - lml_o[0, 0]) / abs(lml_o[0, 0]) < 1e-10
+	mu_fo, cov_o = O.mean_cov(x, L, alpha, xt[:11], spec)
+	assert cov.shape == (11, 11) and rel_err(cov, cov_o) < 1e-10 and rel_err(mu_f, mu_fo) < 1e-10
+	assert rel_err(mu_c, mu_o) < 1e-10 and rel_err(std_c, std_o) < 1e-10          # chunks of 16 test points
+	ov = O.log_marginal(x, y, spec, 0.2, overrides={'0': {'gamma': 0.9}}, weight=0.5)
+	assert abs(lml_ov[0, 0] - ov[0, 0]) / abs(ov[0, 0]) < 1e-10
+	assert abs(lml_again[0, 0] - lml_o[0, 0]) / abs(lml_o[0, 0]) < 1e-10
+	x2, y2 = np.concatenate([x, xt[:5]]), np.concatenate([y, np.cos(xt[:5].sum(axis=1, keepdims=True))])
+	L2, alpha2 = O.fit(x2, y2, spec, 0.2)
+	mu_ao, std_ao = O.mean_std(x2, L2, alpha2, xt[5:], spec)
+	assert rel_err(mu_a, mu_ao) < 1e-10 and rel_err(std_a, std_ao) < 1e-9
+	assert stats["collectives"] > 0 and stats["bcast_bytes"] > 0
 
 
 def test_default_grid():
 	from stpy_amd.parallel.block_cyclic import default_grid
 	assert [default_grid(p) for p in (1, 2, 4, 6, 8)] == [(1, 1), (1, 2), (2, 2), (2, 3), (2, 4)]
+
+
+def _rff_worker(rank, world, port, n, q):
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	try:
+		from stpy_amd.parallel.row_split import ShardedEmbedding, row_range
+
+		class OracleEmbedding:          # stand-in for RFFEmbedding on a box without a GPU: the oracle's embed on the slab
+			def __init__(self, W, m):
+				self.W, self.m = W, m
+
+			def get_m(self):
+				return self.m
+
+			def embed(self, x):
+				return torch.from_numpy(O.rff_embed(x.numpy(), self.W, self.m))
+		rng = np.random.RandomState(3)
+		W = rng.normal(size=(64, 5)) / 0.7
+		x = torch.from_numpy(np.random.RandomState(4).uniform(0, 1, size=(n, 5)))
+		sh = ShardedEmbedding(OracleEmbedding(W, 64))
+		r0, r1, z = sh.embed(x)
+		assert (r0, r1) == row_range(n, rank, world) and z.shape == (r1 - r0, 64)
+		full = sh.embed(x, gather=True)
+		if rank == 0:
+			q.put((full.numpy(), [row_range(n, r, world) for r in range(world)]))
+	finally:
+		dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1000), (4, 700), (3, 128), (8, 262144 // 64)])
+def test_rff_row_split(world, n):
+	"""SURVEY.md section 8e last row: rows split in tile-aligned contiguous slabs, W replicated, no collective on the data
+	path; the slabs tile [0, n) exactly and their concatenation is the single-process embed."""
+	ctx = mp.get_context("spawn")
+	q = ctx.SimpleQueue()
+	port = _free_port()
+	procs = [ctx.Process(target=_rff_worker, args=(r, world, port, n, q)) for r in range(world)]
+	for p in procs:
+		p.start()
+	full, ranges = q.get()          # (read before joining: a large put blocks the child until the pipe is drained)
+	for p in procs:
+		p.join(timeout=120)
+		if p.is_alive():
+			p.terminate()
+	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+	assert ranges[0][0] == 0 and ranges[-1][1] == n and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+	assert all(a % 128 == 0 for a, _ in ranges)
+	sizes = [b - a for a, b in ranges]
+	assert max(sizes) - min(sizes) <= 128 + (128 - n % 128) % 128
+	W = np.random.RandomState(3).normal(size=(64, 5)) / 0.7
+	x = np.random.RandomState(4).uniform(0, 1, size=(n, 5))
+	assert rel_err(full, O.rff_embed(x, W, 64)) < 1e-15          # (BLAS blocks a slab differently from the whole: last-bit differences)

@@ -865,3 +865,63 @@ def test_failed_refit_leaves_the_object_unfitted(S):
 	assert GP.fitted is False and GP._L is None
 	mu, sd = GP.mean_std(xt.cuda())                        # prior branch, no crash inside the C ABI
 	assert float(mu.abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------- quadrature embeddings
+from tests.test_oracle_golden import Q1_CASES, _q1_build, _q1_x          # noqa: E402
+
+
+@pytest.mark.parametrize("tag", Q1_CASES)
+def test_Q1_quadrature_embed(S, tag):
+	"""QuadratureEmbedding.embed and its derived classes (embedding.py:450-466) on the device against the reference's outputs:
+	fp64 at 1e-13, the transposed form, CPU-in/CPU-out and GPU-in/GPU-out, and fp32 against the fp64 oracle."""
+	g = golden("Q1_quadrature")
+	emb = _q1_build(tag)
+	x = _q1_x(g, tag)
+	for cuda in (False, True):
+		z = emb.embed(T(x, cuda))
+		assert z.is_cuda == cuda and tuple(z.shape) == g[tag + "_z"].shape
+		assert rel_err(N(z), g[tag + "_z"]) < 1e-13
+	zt = emb.embed_t(T(x, True))
+	assert tuple(zt.shape) == g[tag + "_z"].T.shape and rel_err(N(zt), g[tag + "_z"].T) < 1e-13
+	z32 = emb.embed(T(x, True).float())
+	assert z32.dtype == torch.float32
+	ref = O.quadrature_embed(x.astype(np.float32).astype(np.float64), emb.W.float().double().numpy(), emb.weights.numpy(), kappa=emb.kappa, cosine=emb.cosine)
+	assert np.abs(N(z32) - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_Q1_quadrature_embed_larger_shapes(S):
+	"""the same entry point at sizes that leave the single-tile regime (n off the tile, m = 2 * 24^2 = 1152 features, d = 2), against the oracle"""
+	import stpy_amd.embeddings.embedding as E
+	rng = np.random.RandomState(3)
+	x = rng.uniform(-1, 1, size=(3001, 2))
+	emb = E.HermiteEmbedding(gamma=0.3, m=2 * 24 ** 2, d=2, kappa=1.7)
+	z = emb.embed(T(x, True))
+	ref = O.quadrature_embed(x, emb.W.numpy(), emb.weights.numpy(), kappa=1.7)
+	assert rel_err(N(z), ref) < 1e-13
+	embc = E.QuadratureEmbedding(gamma=0.3, m=530, d=2, cosine=True)          # q = 23: 529 features, an odd count
+	assert embc.get_m() == 529
+	zc = embc.embed(T(x, True))
+	assert rel_err(N(zc), O.quadrature_embed(x, embc.W.numpy(), embc.weights.numpy(), cosine=True)) < 1e-13
+	zc32 = embc.embed(T(x, True).float())
+	refc = O.quadrature_embed(x.astype(np.float32).astype(np.float64), embc.W.float().double().numpy(), embc.weights.numpy(), cosine=True)
+	assert np.abs(N(zc32) - refc).max() < 2e-5 * np.abs(refc).max()
+
+
+def test_G13_kernelized_features_on_hermite(S):
+	"""the tutorial's comparison (tutorials/fourier-features.ipynb): primal ridge on Hermite quadrature features against the
+	reference's own numbers for it, and the exact GP it approximates (both from the reference)"""
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	import stpy_amd.embeddings.embedding as E
+	g = golden("G13_hermite_features")
+	d = g["x"].shape[1]
+	emb = E.HermiteEmbedding(gamma=float(g["gamma"]), m=int(g["m"]), d=d, kappa=float(g["kappa"]))
+	assert emb.get_m() == int(g["m"])
+	KF = KernelizedFeatures(embedding=emb, m=emb.get_m(), s=float(g["s"]), lam=float(g["lam"]), d=d)
+	KF.fit_gp(T(g["x"], True), T(g["y"], True))
+	mu, std = KF.mean_std(T(g["xtest"], True))
+	assert rel_err(N(mu), g["mu"]) < TOL and rel_err(N(std), g["std"]) < 1e-7
+	GP = S.GaussianProcess(gamma=float(g["gamma"]), s=float(g["s"]), kappa=float(g["kappa"]), kernel_name="squared_exponential", d=d)
+	GP.fit_gp(T(g["x"], True), T(g["y"], True))
+	mu_gp, std_gp = GP.mean_std(T(g["xtest"], True))
+	assert rel_err(N(mu_gp), g["mu_exact_gp"]) < TOL and rel_err(N(std_gp), g["std_exact_gp"]) < TOL

@@ -410,7 +410,7 @@ def test_gram_diag_and_symmetrize(L):
 
 
 # ------------------------------------------------------------------------------------------ factorisation + solves
-def run_potrf(L, K, nb=0, dtype=torch.float64):
+def run_potrf(L, K, nb=0, dtype=torch.float64, flags=0):
 	lib = L.load()
 	n = K.shape[0]
 	Kd = dev(K, dtype)
@@ -418,7 +418,7 @@ def run_potrf(L, K, nb=0, dtype=torch.float64):
 	winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=dtype, device="cuda:0")
 	work = torch.empty((int(lib.stpy_potrf_workspace_bytes(code, n, nb)),), dtype=torch.uint8, device="cuda:0")
 	info = torch.full((1,), -5, dtype=torch.int32, device="cuda:0")
-	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
+	L.check(lib.stpy_potrf(code, n, L.ptr(Kd), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel() * work.element_size(), nb, flags, L.ptr(info), L.stream_ptr()), "potrf")
 	return Kd, winv, int(info.item())
 
 
@@ -718,3 +718,43 @@ def test_combine_and_predict_finish(L, dtype, m, n, ldo, lds):
 	L.check(lib.stpy_predict_finish(code, m, L.ptr(mud), L.ptr(ssd), L.ptr(kdd), 0.5, L.ptr(sg), 0, L.stream_ptr()), "predict_finish")
 	tol = 1e-15 if dtype == torch.float64 else 1e-6
 	assert rel_err(mud.cpu().numpy(), mu * npdt(0.5)) < tol and rel_err(sg.cpu().numpy(), np.sqrt(kd - npdt(0.5) * ss)) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("n,nb", [(128, 0), (1024, 256), (2048, 512), (3200, 1024), (1000, 256), (4096, 0)])
+def test_potrf_and_trsm_beside_update(L, dtype, tol, n, nb):
+	"""STPY_FLAG_BESIDE_UPDATE routes every block of the call through the kernels that fit into what two trailing-update
+	workgroups leave over on a CU: the four-wave / 64-VGPR diagonal-block kernel and the 32 x 128 "sliver" GEMM (fp64; other
+	shapes fall back to the tile kernels).  Same factor, same inverse blocks, same solve as without the flag; the failing
+	pivot is reported at the same index."""
+	lib = L.load()
+	rng = np.random.RandomState(n + 5)
+	K = spd(rng, n)
+	lib.stpy_tune(11, 1 if n != 2048 else 0)          # the four-wave diagonal-block kernel is an off-by-default experiment: keep it correct
+	try:
+		Ld, winv, info = run_potrf(L, K, nb, dtype, flags=L.FLAG_BESIDE_UPDATE)
+	finally:
+		lib.stpy_tune(11, 0)
+	Ld0, winv0, info0 = run_potrf(L, K, nb, dtype, flags=0)
+	assert info == 0 and info0 == 0
+	Lg = np.tril(Ld.cpu().numpy().astype(np.float64))
+	Lref = np.linalg.cholesky(K)
+	assert rel_err(Lg, Lref) < tol
+	assert rel_err(Lg, np.tril(Ld0.cpu().numpy().astype(np.float64))) < tol
+	W = winv.cpu().numpy().astype(np.float64).reshape(-1, 128, 128)
+	for bi in range((n + 127) // 128):
+		c, cb = bi * 128, min(128, n - bi * 128)
+		assert rel_err(W[bi][:cb, :cb], np.linalg.inv(Lref[c:c + cb, c:c + cb])) < tol * 100
+		assert np.all(np.triu(W[bi], 1) == 0)
+	m = 320
+	B = rng.normal(size=(m, n))
+	Bd = dev(B, dtype)
+	code = L.dtype_code(dtype)
+	L.check(lib.stpy_trsm_right_lt(code, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, nb, L.FLAG_BESIDE_UPDATE, None, 0, L.stream_ptr()), "trsm")
+	Xref = sla.solve_triangular(Lref, B.T, lower=True).T
+	assert rel_err(Bd.cpu().numpy().astype(np.float64), Xref) < tol * 10
+	if n >= 1024:          # a matrix that stops being positive definite at a known pivot
+		Kb = K.copy()
+		Kb[700, 700] = -1.0
+		_, _, infob = run_potrf(L, Kb, nb, dtype, flags=L.FLAG_BESIDE_UPDATE)
+		assert infob == 701

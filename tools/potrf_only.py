@@ -6,6 +6,9 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, ".")
 from stpy_amd import _lib as L
 lib = L.load()
 n = int(sys.argv[1]); nb = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for kv in sys.argv[3:]:          # stpy_tune key=value pairs
+	k, v = kv.split("=")
+	lib.stpy_tune(int(k), int(v))
 dev = torch.device("cuda:0")
 x = torch.rand(n, 8, dtype=torch.float64, device=dev) * 2 - 1
 il = torch.full((8,), 0.35, dtype=torch.float64, device=dev)
