@@ -10,10 +10,13 @@ SE kernel gamma = sqrt(d), s = 0.1, kappa = 1, fp64), inputs resident in HBM bef
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (block-cyclic path)
 
 Rank 0 prints ONE JSON line.  `value` = seconds per step (max over ranks), lower is better.
-`roofline` is for the dominant kernel, gemm_nt_kernel<double> (the fp64-MFMA contraction under
-potrf and trsm): achieved = sum of algorithmic flops of its launches / sum of their durations,
-measured live with HIP events recorded on the launch stream inside libstpy_hip (stpy_profile_*).
-`cpu_baseline` times the CPU oracle (numpy/LAPACK restatement, kind "port") on a bounded sample.
+`roofline` is for the dominant kernel family, the fp64-MFMA contraction gemm_nt_dtv_kernel<double,SUB> (+ the sliver / K = 128 /
+tile forms of the panel chain) under potrf and trsm: achieved = sum of the algorithmic flops of its launches / the length of
+the UNION of their intervals (look-ahead launches overlap the trailing update), measured live with HIP events recorded on the
+launch stream inside libstpy_hip (stpy_profile_*); tools/trace_union.py derives the same figure from a rocprofv3 kernel trace
+(profiles/r02_*_union.json).  `extra_configs` holds BASELINE configs 2, 3 and 5 with their own roofline fraction and parity.
+`cpu_baseline` times the CPU oracle (numpy/LAPACK restatement, kind "port") on a bounded sample, checks the HIP path against
+it, and adds the reference-shaped op sequence over an N sweep with a power-law extrapolation.
 """
 import argparse
 import ctypes
@@ -31,6 +34,7 @@ if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6       # MI355X fp64 matrix, vendor dense figure
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X fp32 matrix (MI355X_MICROARCH.md: 155 measured)
 
 
 def synth(n, d, m, device, seed=1234):
@@ -48,9 +52,27 @@ def flops_fit_predict(n, m):
 	return n ** 3 / 3.0 + 2.0 * n * n + float(n) * n * m + 4.0 * n * m
 
 
-def cpu_baseline(d, budget_n=16384, budget_m=2048):
-	"""CPU oracle (port) on a bounded sample of the same workload; ~10-30 s of host work."""
+def _cores():
+	try:
+		return len(os.sched_getaffinity(0))
+	except Exception:
+		return os.cpu_count()
+
+
+def cpu_baseline(d, gp_factory, dev, budget_n=16384, budget_m=2048):
+	"""CPU baseline beside the GPU number, all on a BOUNDED sample (about 20-30 s of host work):
+	  * the Cholesky restatement of the oracle ("port": what estimator.py:35-37 would cost) at N = 16 384, M = 2048 on all
+	    host cores -- the headline `value`; the HIP path runs the same sample and `parity_rel_err` reports mu / sigma against it;
+	  * the reference's OWN operation sequence (dense Sigma^T Sigma, lstsq with N right-hand sides, the per-point loop:
+	    gauss_procc.py:151-163, :347, :376-378) at N in {1024, 2048, 4096} on all cores and at {1024, 2048} on one thread,
+	    a power law fitted through the all-core points and evaluated at N = 65 536 (labelled extrapolated: the reference
+	    cannot allocate that size -- five dense N x N matrices).
+	"""
 	from oracle import gp_oracle as O           # checker/baseline only -- never on the product path
+	try:
+		from threadpoolctl import threadpool_limits
+	except Exception:                               # noqa: BLE001
+		threadpool_limits = None
 	n, m = budget_n, budget_m
 	x, y, xt = synth(n, d, m, "cpu", seed=4321)
 	spec = [("squared_exponential", {"gamma": math.sqrt(d), "kappa": 1.0}, "-")]
@@ -58,14 +80,155 @@ def cpu_baseline(d, budget_n=16384, budget_m=2048):
 	L, alpha = O.fit(x.numpy(), y.numpy(), spec, 0.1)
 	mu, std = O.mean_std(x.numpy(), L, alpha, xt.numpy(), spec)
 	t = time.perf_counter() - t0
-	try:
-		cores = len(os.sched_getaffinity(0))
-	except Exception:
-		cores = os.cpu_count()
-	return {"value": round(t, 4), "unit": "s", "cores": cores, "kind": "port",
-			"sample": "oracle fit+mean_std (numpy/LAPACK Cholesky restatement) at N=%d, M=%d, d=%d fp64; "
-					  "%.3e flop = 1/%.0f of the benchmarked step" % (n, m, d, flops_fit_predict(n, m), flops_fit_predict(65536, 4096) / flops_fit_predict(n, m)),
-			"gflops": round(flops_fit_predict(n, m) / t / 1e9, 1)}
+	del L
+	# the same sample through the HIP path: the CPU leg doubles as a parity check at BASELINE config 2's size
+	gp = gp_factory()
+	gp.fit_gp(x.to(dev), y.to(dev))
+	mu_g, std_g = gp.mean_std(xt.to(dev))
+	rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+	parity = {"mu": rel(mu_g.cpu().numpy(), mu), "sigma": rel(std_g.cpu().numpy(), std)}
+	del gp
+	torch.cuda.empty_cache()
+	out = {"value": round(t, 4), "unit": "s", "cores": _cores(), "kind": "port",
+		   "sample": "oracle fit+mean_std (numpy/LAPACK Cholesky restatement) at N=%d, M=%d, d=%d fp64; "
+					 "%.3e flop = 1/%.0f of the benchmarked step" % (n, m, d, flops_fit_predict(n, m), flops_fit_predict(65536, 4096) / flops_fit_predict(n, m)),
+		   "gflops": round(flops_fit_predict(n, m) / t / 1e9, 1),
+		   "parity_rel_err": {k: float("%.3e" % v) for k, v in parity.items()},
+		   "parity_note": "HIP path vs this CPU result on the same sample (tolerance 1e-8)"}
+
+	# ---- the reference's own op sequence, N sweep + power law.  LAPACK's pivoted QR (gelsy) is BLAS-2 bound and gets SLOWER
+	# with hundreds of threads (measured on the box: N = 2048 6.3 s on 256 threads, 2.5 s on one), so the sweep runs on the
+	# thread count a one-GPU job is entitled to here (16) and on one thread; one all-thread point is kept for the record.
+	def ref_shaped(nn, threads):
+		xs, ys, xts = synth(nn, d, 256, "cpu", seed=4322)
+		t1 = time.perf_counter()
+		if threads and threadpool_limits is not None:
+			with threadpool_limits(limits=threads):
+				O.fit_predict_reference_shaped(xs.numpy(), ys.numpy(), xts.numpy(), spec, 0.1)
+		else:
+			O.fit_predict_reference_shaped(xs.numpy(), ys.numpy(), xts.numpy(), spec, 0.1)
+		return time.perf_counter() - t1
+	nthr = min(16, _cores())
+	ref_shaped(256, nthr)          # untimed: first-call costs of the LAPACK drivers
+	sweep, one = {}, {}
+	spent = 0.0
+	for nn in (1024, 2048, 4096):
+		if spent > 7.0:          # bounded: a slow host stops after the sizes that fit the budget
+			break
+		sweep[nn] = ref_shaped(nn, nthr)
+		spent += sweep[nn]
+	for nn in (1024, 2048):
+		if threadpool_limits is None or spent > 16.0:
+			break
+		one[nn] = ref_shaped(nn, 1)
+		spent += one[nn]
+	ref = {"kind": "port of the reference's op sequence (gauss_procc.py:151-163,:347,:376-378: dense Sigma^T Sigma, gelsy lstsq with N right-hand sides, per-point loop)",
+		   "threads": nthr, "seconds_by_N": {str(k): round(v, 3) for k, v in sweep.items()}, "one_thread_seconds_by_N": {str(k): round(v, 3) for k, v in one.items()}, "m_test": 256}
+	if spent < 20.0:
+		ref["all_%d_threads_seconds_at_N1024" % _cores()] = round(ref_shaped(1024, 0), 3)
+	if len(sweep) >= 2:
+		ks = sorted(sweep)[-2:] if len(sweep) > 2 else sorted(sweep)          # the two largest sizes: the small one is overhead-dominated
+		b, a = np.polyfit(np.log([float(k) for k in ks]), np.log([sweep[k] for k in ks]), 1)
+		ref["power_law"] = {"exponent": round(float(b), 3), "fit_points": ks}
+		ref["extrapolated_s_at_N65536"] = round(float(math.exp(a) * 65536.0 ** b), 1)
+		ref["extrapolation_note"] = "extrapolated, not measured: at N = 65 536 the sequence needs >= 5 dense N x N fp64 matrices (172 GB)"
+	out["reference_shaped"] = ref
+	return out
+
+
+def extra_configs(dev, lib):
+	"""The other single-GPU BASELINE.json configurations (parity-test cases, not the bench line), each timed over a few
+	repetitions with inputs resident, with the roofline that bounds it and a parity figure measured in the same run."""
+	from stpy_amd import GaussianProcess, RFFEmbedding
+	out = {}
+
+	def timed(fn, reps=3):
+		fn()
+		torch.cuda.synchronize()
+		ts = []
+		for _ in range(reps):
+			t0 = time.perf_counter()
+			r = fn()
+			torch.cuda.synchronize()
+			ts.append(time.perf_counter() - t0)
+		return min(ts), r
+
+	# C2: N = 16 384, d = 8, SE, fp64
+	n, d, m = 16384, 8, 4096
+	x, y, xt = synth(n, d, m, dev)
+	gp = GaussianProcess(gamma=math.sqrt(d), s=0.1, kernel_name="squared_exponential", d=d)
+
+	def c2():
+		gp.fit_gp(x, y)
+		return gp.mean_std(xt)
+	t, (mu, std) = timed(c2, reps=5)
+	idx = torch.arange(0, n, 8, device=dev)
+	mu_tr, _ = gp.mean_std(x[idx])
+	expect = y[idx] - 0.01 * gp.A.reshape(-1, 1).to(dev)[idx]
+	F = flops_fit_predict(n, m)
+	out["C2"] = {"workload": "N=16384 d=8 SE fp64 fit_gp+mean_std, M=4096", "seconds": round(t, 5), "bound": "mfma", "achieved": round(F / t / 1e12, 2),
+				 "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(F / t / 1e12 / PEAK_FP64_MFMA_TFLOPS, 4),
+				 "parity": {"training_point_identity_rel_err": float("%.2e" % float(torch.norm(mu_tr - expect) / torch.norm(expect))),
+							"note": "mean(x_i) = y_i - s^2 alpha_i through the prediction path; vs-oracle parity of this size: cpu_baseline.parity_rel_err and tests/test_gpu_configs.py"}}
+	del gp
+	torch.cuda.empty_cache()
+
+	# C3: N = 65 536, d = 16, Matern-5/2, fp32 + log_marginal; parity against the fp64 HIP path on the same inputs
+	n, d, m = 65536, 16, 4096
+	x, y, xt = synth(n, d, m, dev)
+	x32, y32, xt32 = x.float(), y.float(), xt.float()
+	kw = dict(gamma=math.sqrt(d), s=0.3, kernel_name="matern", nu=2.5, d=d)
+	g64 = GaussianProcess(**kw)
+	g64.fit_gp(x32.double(), y32.double())
+	mu64, sd64 = g64.mean_std(xt32.double())
+	lm64 = float(g64.log_marginal(g64.kernel_object, {}, 1.0))
+	del g64
+	torch.cuda.empty_cache()
+	g32 = GaussianProcess(**kw)
+
+	def c3():
+		g32.fit_gp(x32, y32)
+		mu, sd = g32.mean_std(xt32)
+		return mu, sd, g32.log_marginal(g32.kernel_object, {}, 1.0)
+	t, (mu32, sd32, lm32) = timed(c3, reps=2)
+	rel = lambda a, b: float(torch.norm(a.double() - b) / torch.norm(b))
+	out["C3"] = {"workload": "N=65536 d=16 Matern-5/2 fp32 fit_gp+mean_std+log_marginal, M=4096, s=0.3", "seconds": round(t, 4), "bound": "mfma",
+				 "achieved": round(F_fp(n, m) / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(F_fp(n, m) / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+				 "parity": {"vs_fp64_hip_rel_err": {"mu": float("%.2e" % rel(mu32, mu64)), "sigma": float("%.2e" % rel(sd32, sd64)),
+													"lml": float("%.2e" % (abs(float(lm32) - lm64) / abs(lm64)))}, "tolerance": 1e-3}}
+	del g32, mu64, sd64
+	torch.cuda.empty_cache()
+
+	# C5: RFF embed N = 262 144, d = 64, m = 32 768, fp32 at the C ABI (output buffer allocated once)
+	n, d, m = 262144, 64, 32768
+	gen = torch.Generator().manual_seed(1237)
+	xr = torch.rand(n, d, generator=gen, dtype=torch.float32).to(dev)
+	np.random.seed(1237)
+	emb = RFFEmbedding(gamma=math.sqrt(d), m=m, d=d)
+	W = emb.W.float().to(dev)
+	z = torch.empty((n, m), dtype=torch.float32, device=dev)
+	from stpy_amd import _lib as L
+
+	def c5():
+		L.check(lib.stpy_rff_embed(L.F32, L.ptr(xr), n, d, d, L.ptr(W), d, m, None, None, math.sqrt(2.0 / m), L.ptr(z), m, 0, L.stream_ptr()), "rff")
+	t, _ = timed(c5, reps=5)
+	rows = torch.cat([torch.arange(0, 64), torch.arange(n // 2, n // 2 + 64), torch.arange(n - 64, n)]).to(dev)
+	from oracle import gp_oracle as O          # checker only
+	ref = O.rff_embed(xr[rows].double().cpu().numpy(), W.double().cpu().numpy(), m)
+	err = float(np.abs(z[rows].cpu().numpy() - ref).max() / math.sqrt(2.0 / m))
+	bytes_ = n * m * 4 + n * d * 4 + m * d * 4
+	flops = 2.0 * n * d * m
+	out["C5"] = {"workload": "RFF embed N=262144 d=64 m=32768 fp32 (stpy_rff_embed, output resident)", "seconds": round(t, 5),
+				 "bound": "mfma (fp32: 7.0 ms) > hbm write (5.4 ms at 6.3 TB/s)", "achieved": round(flops / t / 1e12, 1), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+				 "frac": round(flops / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "hbm_tb_s": round(bytes_ / t / 1e12, 2), "hbm_frac_of_8tb_s": round(bytes_ / t / 8e12, 4),
+				 "parity": {"max_abs_err_over_amplitude": float("%.2e" % err), "rows_checked": int(rows.numel()), "tolerance": 2e-5}}
+	del z
+	torch.cuda.empty_cache()
+	return out
+
+
+def F_fp(n, m):
+	return flops_fit_predict(n, m)
 
 
 def main():
@@ -78,6 +241,7 @@ def main():
 	ap.add_argument("--m", type=int, default=4096)
 	ap.add_argument("--nb", type=int, default=0)
 	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-extra-configs", action="store_true")
 	args = ap.parse_args()
 
 	world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +280,7 @@ def main():
 
 	if dist_path:
 		from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
-		gp = DistributedGaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+		gp = DistributedGaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d, force_path=force_dist)
 	else:
 		gp = GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
 	gp.nb = args.nb
@@ -176,6 +340,17 @@ def main():
 	except Exception:
 		traffic = None
 
+	# ---- multi-GPU: what moved and how busy every rank's MFMA GEMM was (gathered; one small host object per rank)
+	dist_info = None
+	if dist_path:
+		mine = {"rank": rank, "gemm_busy_ms_per_step": round(ub.value / args.steps, 2),
+				"bcast_MB_per_step": round(gp.stats["bcast_bytes"] / 1e6 / (args.steps + args.warmup), 1),
+				"reduce_MB_per_step": round(gp.stats["reduce_bytes"] / 1e6 / (args.steps + args.warmup), 1),
+				"collectives_per_step": gp.stats["collectives"] // max(args.steps + args.warmup, 1)}
+		gathered = [None] * world
+		torch.distributed.all_gather_object(gathered, mine)
+		dist_info = {"rccl_ranks": world if backend == "nccl" else 0, "backend": backend, "grid": "%dx%d" % (gp.Pr, gp.Pc), "nb_dist": gp.NB, "per_rank": gathered}
+
 	if rank == 0:
 		F = flops_fit_predict(n, m)
 		out = {
@@ -196,8 +371,14 @@ def main():
 			"breakdown_ms_per_step": {k: round(v[0] / args.steps, 2) for k, v in pr.items()},
 			"result_check": {"mu_norm": float(torch.norm(mu)), "std_mean": float(std.mean()), "nan": bool(torch.isnan(std).any())},
 		}
+		if dist_info is not None:
+			out["multi_gpu"] = dist_info
 		if world == 1 and not args.no_cpu_baseline:
-			out["cpu_baseline"] = cpu_baseline(d)
+			del gp
+			torch.cuda.empty_cache()
+			if not args.no_extra_configs:
+				out["extra_configs"] = extra_configs(dev, lib)
+			out["cpu_baseline"] = cpu_baseline(d, lambda: GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d), dev)
 		print(json.dumps(out), flush=True)
 	if dist_path:
 		torch.distributed.destroy_process_group()

@@ -244,6 +244,37 @@ def mean_std(x, L, alpha, xtest, spec):
 	return mu.reshape(-1, 1), std.reshape(-1, 1)
 
 
+def fit_predict_reference_shaped(x, y, xtest, spec, s):
+	"""
+	The reference's OWN operation sequence for fit_gp + mean_std (what the CPU baseline of bench.py times), as opposed to
+	the Cholesky restatement above which is mathematically equal and far cheaper:
+	  gauss_procc.py:151-163  Sigma = s * eye(n) materialised, K = k(x,x) + Sigma^T @ Sigma  (a dense n^3 product of a diagonal);
+	  gauss_procc.py:176      fit_gp ends with mean_std(x): K* = k(x, x) (n x n), the per-point Python loop for diag k(x*,x*)
+	                          (:347), A = lstsq(K, y) (:376), B = lstsq(K, K*^T)^T with n right-hand sides (:378),
+	                          mean = K* A, variance = diag - einsum(B, K*^T)  (:381-395);
+	  then the user's mean_std(xtest) repeats the last step with M right-hand sides (and solves for A again, reuse=False).
+	torch.linalg.lstsq on CPU uses LAPACK gelsy (complete orthogonal factorisation); scipy's driver of the same name is used here.
+	Returns (mu, std) for xtest.
+	"""
+	x = np.asarray(x, dtype=np.float64)
+	y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+	n = x.shape[0]
+	Sigma = s * np.eye(n)
+	K = kernel(x, x, spec) + Sigma.T @ Sigma
+
+	def mean_std_sub(xt):
+		Ks = kernel(x, xt, spec)
+		kd = kernel_diag(xt, spec)
+		A = sla.lstsq(K, y, lapack_driver="gelsy", check_finite=False)[0]
+		B = sla.lstsq(K, Ks.T, lapack_driver="gelsy", check_finite=False)[0].T
+		mean = Ks @ A
+		var = kd.reshape(-1, 1) - np.einsum('ij,ji->i', B, Ks.T).reshape(-1, 1)
+		with np.errstate(invalid="ignore"):
+			return mean, np.sqrt(var)
+	mean_std_sub(x)                                   # gauss_procc.py:176
+	return mean_std_sub(np.asarray(xtest, dtype=np.float64))
+
+
 def mean_cov(x, L, alpha, xtest, spec):
 	"""gauss_procc.py:396-399 (full=True): (mu, K** - K* K^-1 K*^T)."""
 	Ks = kernel(x, xtest, spec)

@@ -33,6 +33,7 @@ import math
 import torch
 
 from .. import _lib
+from ..estimator import Estimator, Euclidean
 from ..kernels import KernelFunction
 
 
@@ -58,7 +59,7 @@ def _tile_pad(n):
 	return -(-int(n) // 128) * 128
 
 
-class GaussianProcess:
+class GaussianProcess(Estimator):
 
 	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", diameter=1.0,
 				 groups=None, bounds=None, nu=1.5, kernel=None, d=1, power=2, lam=1., loss='squared', huber_delta=1.35,
@@ -617,76 +618,39 @@ class GaussianProcess:
 						maxiter=1000, mingradnorm=1e-4, verbose=False, optimizer="pymanopt", scale=1., weight=1., save=False,
 						save_name='model.np', init_func=None, bounds=None, parallel=False, cores=None):
 		"""
-		gauss_procc.py:640-702 + estimator.py:141-256 for ``type`` in {"bandwidth", "bandwidth+noise"}:
-		minimise log_marginal over the kernel lengthscales ('gamma' / 'ard_gamma' of every kernel item)
-		and optionally the noise std, ``restarts`` times, keep the best, write it back into
-		``kernel_object.params_dict`` / ``self.s`` and refit.  Objective and gradient are the device
-		evidence and its analytic gradient (every evaluation is a full Gram + Cholesky [+ inverse]).
-		The descent itself is L-BFGS as in the reference's "pytorch-minimize" branch: torchmin when it
-		is installed, otherwise scipy's L-BFGS-B on the same objective/gradient (also used for
-		optimizer="pymanopt", whose steepest-descent solver is outside this path).
+		gauss_procc.py:640-702 for ``type`` in {"bandwidth", "bandwidth+noise"}: builds the ``params`` dictionary -- every
+		kernel item's 'gamma' / 'ard_gamma' on a Euclidean factor, optionally the noise std under the key 'likelihood' -- and
+		hands it to ``Estimator.optimize_params_general`` (stpy_amd/estimator.py), which minimises ``log_marginal`` over
+		``restarts`` starting points, writes the best one back into ``kernel_object.params_dict`` / ``self.s`` and refits.
+		Objective and gradient are the device evidence and its analytic gradient (every evaluation is a full Gram +
+		Cholesky [+ inverse]).  The rotation / group / covariance searches of the reference (Stiefel and PSD manifolds,
+		discrete group enumeration) are outside the hot path.
 		"""
-		import scipy.optimize
 		if regularizer is not None:
-			raise NotImplementedError("regularised hyper-parameter search is outside the stpy_amd hot path")
+			if regularizer[0] == "spectral_norm":          # gauss_procc.py:645-653
+				regularizer_func = lambda S: regularizer[1] * torch.norm(1 / S.reshape(1, -1), p='nuc')
+			elif regularizer[0] == 'lasso':
+				regularizer_func = lambda S: regularizer[1] * torch.norm(1 / S, p=1)
+			else:
+				regularizer_func = None
+		else:
+			regularizer_func = None
 		if type not in ("bandwidth", "bandwidth+noise"):
+			if type in ("rots", "groups", "covariance"):
+				raise NotImplementedError("optimize_params(type='%s') is outside the stpy_amd hot path" % type)
 			raise AttributeError("This quick-optimization is not implemented.")          # gauss_procc.py:698
-		ko = self.kernel_object
-		slots = []                                     # (key, var_name, dim)
-		for key, dict2 in ko.params_dict.items():
+		params = {}
+		for key, dict2 in self.kernel_object.params_dict.items():
 			if 'gamma' in dict2.keys():
-				slots.append((key, 'gamma', 1))
+				params[key] = {'gamma': (init_func, Euclidean(1), bounds)}
 			elif 'ard_gamma' in dict2.keys():
-				slots.append((key, 'ard_gamma', len(dict2['group'])))
+				params[key] = {'ard_gamma': (init_func, Euclidean(len(dict2['group'])), bounds)}
 		if type == "bandwidth+noise":
-			slots.append(('likelihood', 'sigma', 1))
-		dims = np.cumsum([0] + [sl[2] for sl in slots]).astype(int)
-		dim = int(dims[-1])
-		s_backup = self.s
-
-		def cost(x):
-			input_dict = ko.params_dict
-			for c, (key, var, _) in enumerate(slots):
-				if key != "likelihood":
-					input_dict[key][var] = x[dims[c]:dims[c + 1]]
-				else:
-					self.s = x[dims[c]:dims[c + 1]]
-			return self.log_marginal(ko, input_dict, weight)
-
-		def fun(xnp):
-			xt = torch.tensor(np.asarray(xnp, dtype=np.float64), dtype=torch.float64, requires_grad=True)
-			f = cost(xt)
-			f.backward()
-			return float(f.detach().reshape(-1)[0]), xt.grad.numpy().astype(np.float64)
-
-		objective_values, objective_params = [], []
-		for rep in range(restarts):
-			if init_func is None:
-				x_init = (torch.randn(size=(dim, 1)).double().view(-1) ** 2 * scale).numpy()
-				if type == "bandwidth+noise":
-					x_init[-1] = float(torch.as_tensor(s_backup).reshape(-1)[0])          # estimator.py: init_func_noise = lambda x: self.s
-			else:
-				x_init = np.asarray(init_func(dim), dtype=np.float64).reshape(-1)
-			res = scipy.optimize.minimize(fun, x_init, jac=True, method='L-BFGS-B', bounds=bounds,
-										  options={'maxiter': maxiter, 'gtol': mingradnorm, 'ftol': 1e-12})
-			if verbose:
-				print("restart", rep, "f =", res.fun, "x =", res.x, res.message)
-			objective_params.append(res.x)
-			objective_values.append(res.fun)
-		best = int(np.argmin(objective_values))
-		x_best = torch.from_numpy(np.asarray(objective_params[best], dtype=np.float64))
-		for c, (key, var, _) in enumerate(slots):
-			if key == "likelihood":
-				self.s = x_best[dims[c]:dims[c + 1]]
-			else:
-				ko.params_dict[key][var] = x_best[dims[c]:dims[c + 1]]
-		self.optimization_trace = {"values": objective_values, "params": objective_params, "best": best}
-		self.back_prop = False                         # estimator.py:250
-		self.fitted = False
-		if verbose:
-			print(self.description())
-		self.fit_gp(self.x, self.y)
-		return True
+			s0 = self.s
+			params['likelihood'] = {'sigma': ((lambda k: s0), Euclidean(1), None)}          # init_func_noise = lambda x: self.s
+		return self.optimize_params_general(params=params, restarts=restarts, optimizer=optimizer, regularizer_func=regularizer_func,
+											maxiter=maxiter, mingradnorm=mingradnorm, verbose=verbose, scale=scale, weight=weight,
+											save=save, save_name=save_name, parallel=parallel, cores=cores)
 
 	def load_data(self, d):
 		"""estimator.py:28-30."""

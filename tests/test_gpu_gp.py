@@ -925,3 +925,50 @@ def test_G13_kernelized_features_on_hermite(S):
 	GP.fit_gp(T(g["x"], True), T(g["y"], True))
 	mu_gp, std_gp = GP.mean_std(T(g["xtest"], True))
 	assert rel_err(N(mu_gp), g["mu_exact_gp"]) < TOL and rel_err(N(std_gp), g["std_exact_gp"]) < TOL
+
+
+def test_estimator_base_and_general_driver(S):
+	"""GaussianProcess derives from Estimator as in the reference (gauss_procc.py:18) and Estimator.optimize_params_general
+	(estimator.py:42-257) drives the device evidence directly from a ``params`` dictionary: the steepest-descent branch
+	("pymanopt"; written out here when the package is absent), the L-BFGS branch with the noise as a second variable, and the
+	reference's bisection on one bounded scalar."""
+	from stpy_amd.estimator import Estimator, Euclidean
+	assert issubclass(S.GaussianProcess, Estimator)
+	rng = np.random.RandomState(18)
+	n, d = 180, 2
+	x = torch.from_numpy(rng.uniform(-1, 1, size=(n, d)))
+	y = torch.sin(3 * x[:, :1]) * torch.cos(2 * x[:, 1:2]) + 0.1 * torch.from_numpy(rng.normal(size=(n, 1)))
+
+	def torch_opt(noise):
+		import scipy.optimize
+
+		def fun(v):
+			t = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+			f = _torch_lml(x, y, t[1] if noise else 0.1, 1.0, "se", t[0], 1.0)
+			f.backward()
+			return float(f.detach()), t.grad.numpy()
+		return scipy.optimize.minimize(fun, np.array([0.3, 0.1] if noise else [0.3]), jac=True, method='L-BFGS-B', options={'gtol': 1e-6, 'ftol': 1e-14})
+	ref = torch_opt(False)
+	GP = S.GaussianProcess(gamma=0.3, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP.fit_gp(x, y)
+	ok = GP.optimize_params_general(params={'0': {'gamma': (lambda k: np.full(k, 0.3), Euclidean(1), None)}}, restarts=1, optimizer="pymanopt",
+									maxiter=300, mingradnorm=1e-5)
+	assert ok is True and GP.fitted and GP.back_prop is False
+	assert abs(lml(GP) - ref.fun) / abs(ref.fun) < 1e-7
+	assert abs(abs(float(GP.kernel_object.params_dict['0']['gamma'].reshape(-1)[0])) - abs(ref.x[0])) / abs(ref.x[0]) < 1e-3
+	# two variables: lengthscale + noise (each reads its OWN slice of x)
+	ref2 = torch_opt(True)
+	GP2 = S.GaussianProcess(gamma=0.3, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP2.fit_gp(x, y)
+	GP2.optimize_params(type="bandwidth+noise", restarts=1, optimizer="pytorch-minimize", init_func=lambda k: np.full(k, 0.3), maxiter=300, mingradnorm=1e-6)
+	assert abs(lml(GP2) - ref2.fun) / abs(ref2.fun) < 1e-6
+	assert abs(abs(float(torch.as_tensor(GP2.s).reshape(-1)[0])) - abs(ref2.x[1])) / abs(ref2.x[1]) < 1e-2
+	# bisection (reference semantics: root of the cost on [a, b]); the evidence of this problem is negative at both ends -> 'stop' returns a
+	GP3 = S.GaussianProcess(gamma=0.3, s=0.1, kappa=1.0, kernel_name="squared_exponential", d=d)
+	GP3.fit_gp(x, y)
+	fa = float(GP3.log_marginal(GP3.kernel_object, {'0': {'gamma': torch.tensor([0.2]).double()}}, 1.0))
+	GP3.optimize_params_general(params={'0': {'gamma': (None, Euclidean(1), (0.2, 2.0))}}, restarts=1, optimizer="bisection")
+	g3 = float(GP3.kernel_object.params_dict['0']['gamma'].reshape(-1)[0])
+	assert (fa < 0 and g3 == 0.2) or abs(lml(GP3)) < 1e-6 * max(1.0, abs(fa))
+	with pytest.raises(AssertionError):
+		GP3.optimize_params_general(params={'0': {'gamma': (None, Euclidean(1), None)}}, optimizer="nope")

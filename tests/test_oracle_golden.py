@@ -322,3 +322,12 @@ def test_host_quadrature_tables_match_reference(tag):
 	assert emb.W.shape == g[tag + "_W"].shape and rel_err(emb.W.numpy(), g[tag + "_W"]) < 1e-14
 	assert rel_err(emb.weights.numpy(), g[tag + "_weights"]) < 1e-13
 	assert emb.cosine == tag.startswith("quad_cos")
+
+
+def test_reference_shaped_sequence_matches_reference():
+	"""the CPU-baseline restatement of the reference's own op sequence (dense Sigma^T Sigma, lstsq with n right-hand sides, the
+	per-point loop) reproduces the reference's numbers, like the Cholesky restatement does"""
+	g = golden("G2_se_d8")
+	spec = [("squared_exponential", {"gamma": float(g["gamma"]), "kappa": float(g["kappa"])}, "-")]
+	mu, std = O.fit_predict_reference_shaped(g["x"], g["y"], g["xtest"], spec, float(g["s"]))
+	assert rel_err(mu, g["mu"]) < TOL and rel_err(std, g["std"]) < TOL

@@ -1,0 +1,21 @@
+#!/bin/bash
+# The round's profiling passes on the GPU box (run from the repo root through gpurun); raw output under gpurun_out/prof_r02/,
+# the summaries that DESIGN.md / bench lines cite are copied into profiles/ afterwards (tools/trace_union.py, tools/pmc_traffic.py).
+# rocprofv3 is given the program itself after `--`; counters are collected in their own passes (no tracing options with --pmc).
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_r02
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $R
+echo "== bench line (not profiled)"; python3 bench.py --steps 5 --warmup 2 > $O/bench_line.json 2> $O/bench_line.err || exit 1
+tail -c 600 $O/bench_line.json; echo
+echo "== kernel trace + stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs > $O/kt_line.json 2> $O/kt.err || exit 1
+echo "== pmc FETCH_SIZE"; rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 1
+echo "== pmc WRITE_SIZE"; rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs > $O/pmc_write.json 2> $O/pmc_write.err || exit 1
+echo "== gram / rff: kernel stats, then counters"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/gr_kt -o gr -- python3 tools/gram_rff_only.py > $O/gr_kt.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/gr_write -o gr -- python3 tools/gram_rff_only.py > $O/gr_write.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gr_fetch -o gr -- python3 tools/gram_rff_only.py > $O/gr_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/gr_sq -o gr -- python3 tools/gram_rff_only.py > $O/gr_sq.log 2>&1 || exit 1
+ls -R $O | head -60
