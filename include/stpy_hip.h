@@ -237,7 +237,10 @@ void stpy_profile_enable(int enable);
  * 7 diagonal block first below this order (8192) · 8 one-volley K = 128 kernel up to this many 64-tiles (768; 0 never) ·
  * 9 fp32 RFF route (1: streaming kernel for large d = 64 shapes + tile kernel; 2: tile kernel only; 0: GEMM epilogue) ·
  * 10 look-ahead panels run in "beside" mode (kernels that fit into what two update workgroups leave over on a CU) while the
- *    trailing update has at least this many rows (0: always) · 11 the four-wave / 64-VGPR diagonal-block kernel in that mode (0) */
+ *    trailing update has at least this many rows (0: always) · 11 the four-wave / 64-VGPR diagonal-block kernel in that mode (0) ·
+ * 12 / 13 potrf updates trailing matrices of at most / at least this many rows on a stream masked off one CU per XCD and runs
+ *    the diagonal-block kernel on those reserved CUs (0 = never / 2048) · 14 / 15 adaptive panel width of potrf: 256 columns while
+ *    at most this many rows are left, 512 up to the second value, 1024 beyond (2048 / 16384) */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */
 int stpy_tune_get(int key);

@@ -350,6 +350,10 @@ void stpy_tune(int key, int value)
 	if (key == 9) g_rff_tile = value;
 	if (key == 10) g_potrf_beside_min = value;
 	if (key == 11) g_potf2_sliver = value;
+	if (key == 12) g_potrf_reserve_below = value;
+	if (key == 13) g_potrf_reserve_above = value;
+	if (key == 14) g_potrf_nb256_upto = value;
+	if (key == 15) g_potrf_nb512_upto = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
@@ -368,6 +372,10 @@ int stpy_tune_get(int key)
 	case 9: return g_rff_tile;
 	case 10: return g_potrf_beside_min;
 	case 11: return g_potf2_sliver;
+	case 12: return g_potrf_reserve_below;
+	case 13: return g_potrf_reserve_above;
+	case 14: return g_potrf_nb256_upto;
+	case 15: return g_potrf_nb512_upto;
 	default: return -1;
 	}
 }

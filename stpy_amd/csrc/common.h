@@ -11,8 +11,9 @@ namespace stpy {
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
 // panel width when the caller passes nb = 0: narrower panels shorten the latency-bound panel chain, which a
-// small trailing matrix cannot hide (measured, tools/phase_bench.py: N = 8k / 16k: 256; 32k: 512; 64k: 1024)
-inline int potrf_auto_nb(int64_t n) { return n <= 16384 ? 256 : (n <= 32768 ? 512 : POTRF_DEFAULT_NB); }
+// small trailing matrix cannot hide; the thresholds are set (and documented with their measurements) in potrf.hip
+extern int g_potrf_nb256_upto, g_potrf_nb512_upto;          // stpy_tune keys 14 / 15
+inline int potrf_auto_nb(int64_t n) { return n <= g_potrf_nb256_upto ? 256 : (n <= g_potrf_nb512_upto ? 512 : POTRF_DEFAULT_NB); }
 
 extern int g_gemm_stagger;
 extern int g_gemm_exp;
@@ -28,6 +29,12 @@ int check_launch(const char* what);
 struct LookAhead {
 	hipStream_t side = nullptr;
 	hipEvent_t col_ready = nullptr, panel_done = nullptr, trail_done = nullptr;
+	// "reserved" mode of potrf: update stream masked off one CU per XCD, diagonal-block stream masked onto those CUs
+	hipStream_t upd = nullptr, diag = nullptr;
+	hipEvent_t ev_diag = nullptr, ev_gemm = nullptr, ev_mode = nullptr;
+};
+	hipEvent_t slab_done[MAX_SLABS - 1] = {nullptr, nullptr, nullptr};
+	hipEvent_t fork = nullptr;
 };
 int lookahead_acquire(hipStream_t caller, LookAhead** out);
 
@@ -94,7 +101,7 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
 extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking;
-extern int g_potrf_diag_first_below, g_potrf_beside_min;
+extern int g_potrf_diag_first_below, g_potrf_beside_min, g_potrf_reserve_below, g_potrf_reserve_above;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
 template <typename T>

@@ -167,6 +167,10 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 // block column j, no workgroup barrier is needed while the eight columns advance.
 // ------------------------------------------------------------------------------------------
 constexpr int SB = 16, NSB = IB / SB, WLD = 17;
+#ifdef STPY_STAMPS
+__device__ unsigned long long* stpy_dbg_potf2 = nullptr;      // diagnostic builds only: [count, pad, 8 stamps x 1000]
+extern "C" void stpy_debug_set_potf2_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(stpy_dbg_potf2), &p, sizeof(p)); }
+#endif
 constexpr int TRI = IB * (IB + 1) / 2;
 
 __device__ __forceinline__ int tri(int i, int k) { return (i * (i + 1) >> 1) + k; }      // k <= i
@@ -197,6 +201,9 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	T* S = reinterpret_cast<T*>(smem_raw);          // [TRI] packed lower triangle
 	T* WD = S + TRI;                                // [8][16][WLD]
 	T* SC = WD + NSB * SB * WLD;                    // [8 waves][16][WLD] scratch (fp32 operand re-layout only)
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int r16 = lane & 15, g = lane >> 4;
 
@@ -217,6 +224,9 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 		}
 	}
 	__syncthreads();
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
 	// ---- 16x16 diagonal sub-block kb (ONE wave): Cholesky factor and its inverse together.
 	// Lane (q, i) = (lane >> 4, lane & 15) holds row i, columns 4q..4q+3, of the block (a[]) and of the inverse being
@@ -331,6 +341,9 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 		}
 	}
 	__syncthreads();
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
 	// ---- write L back (and the panel copy with explicit zeros above the diagonal); inverse(L):
 	// ---- zeros above the diagonal and the diagonal sub-blocks now, off-diagonal blocks below
@@ -346,6 +359,9 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 		else if (bj == bi) W[idx] = WD[(bi * SB + (i & 15)) * WLD + (j & 15)];
 	}
 	// (no barrier needed: the inverse below reads S and WD only, and writes W blocks nobody else touches)
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t3 = __builtin_amdgcn_s_memrealtime();
+#endif
 
 	// ---- triangular inverse, block column `wave`; W_ij goes to global memory, later steps of the
 	// ---- same wave read W_kj back from there
@@ -409,6 +425,14 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 		}
 		}
 	}
+#ifdef STPY_STAMPS
+	__syncthreads();
+	if (tid == 0 && stpy_dbg_potf2) {
+		const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+		const unsigned slot = atomicAdd((unsigned*)stpy_dbg_potf2, 1u);
+		if (slot < 1000) { unsigned long long* d = stpy_dbg_potf2 + 2 + 8 * slot; d[0] = stamp_t0; d[1] = stamp_t1; d[2] = stamp_t2; d[3] = stamp_t3; d[4] = t1; }
+	}
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -649,6 +673,17 @@ int g_potrf_diag_first_below = 8192;     // stpy_tune key 7
 // look-ahead panel) potrf takes 10.2 / 36.7 / 194.4 / 1396 ms at N = 8192 / 16 384 / 32 768 / 65 536 against
 // 11.6 / 40.4 / 206.5 / 1411 ms without the beside mode.
 int g_potrf_beside_min = 0;
+// stpy_tune keys 12 / 13: trailing matrices with at most / at least this many rows are updated in reserved mode (see potrf());
+// 12 = 0 (the default) switches the mode off.  Measured, one process (tools/potrf_sweep.py, gpurun_out/potrf_sweep6.log): with the
+// mode on for every trailing matrix <= 24 576 rows potrf takes 10.5 / 38.7 / 208.0 / 1385 ms at N = 8192 / 16 384 / 32 768 /
+// 65 536 against 10.1 / 36.5 / 195.9 / 1371 ms without: the diagonal-block kernel does run at its stand-alone speed on its
+// reserved CU, but the update loses more (3 % of the CUs, 62 instead of 64 slots per XCD under a 64-tile super-tile map, and two
+// event hand-overs per 128-column block) than the chain gains.  Kept switchable; not used.
+int g_potrf_reserve_below = 0, g_potrf_reserve_above = 2048;
+// stpy_tune keys 14 / 15.  With the panel products in "beside" mode the chain of a wide panel is cheaper than it was, and wide
+// panels win (tools/potrf_sweep.py, gpurun_out/potrf_sweep8.log / 10.log, one process: N = 16 384 36.5 -> 34.4 ms, 32 768 196 -> 190 ms
+// against the former 16384 / 32768 thresholds; N = 65 536 unchanged within 0.2 %)
+int g_potrf_nb256_upto = 2048, g_potrf_nb512_upto = 16384;
 namespace {
 struct LaKey { int device; hipStream_t stream; bool operator<(const LaKey& o) const { return device != o.device ? device < o.device : stream < o.stream; } };
 std::mutex g_la_mutex;
@@ -674,6 +709,22 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 		delete la;
 		return -1002;
 	}
+	// "reserved" mode (potrf, mid-size trailing matrices): the trailing update runs on a stream masked OFF one CU per XCD and
+	// the diagonal-block kernel on a stream masked ONTO those eight CUs.  Mask bits are dealt round-robin over the eight XCCs
+	// (tools/cumask_probe.hip: bits 0-7 = se0.cu0 of xcc0..7; an XCC whose bits are all clear gets ALL its CUs, so no XCC is
+	// ever left empty).  Failure to create them only switches the mode off.
+	{
+		unsigned m_upd[8], m_diag[8];
+		for (int w = 0; w < 8; ++w) { m_upd[w] = 0xffffffffu; m_diag[w] = 0u; }
+		m_upd[0] = 0xffffff00u;
+		m_diag[0] = 0x000000ffu;
+		if (hipExtStreamCreateWithCUMask(&la->upd, 8, m_upd) != hipSuccess || hipExtStreamCreateWithCUMask(&la->diag, 8, m_diag) != hipSuccess ||
+		    hipEventCreateWithFlags(&la->ev_diag, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&la->ev_gemm, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&la->ev_mode, hipEventDisableTiming) != hipSuccess) {
+			(void)hipGetLastError();
+			la->upd = la->diag = nullptr;
+		}
+	}
 	g_la_map[key] = la;
 	*out = la;
 	return 0;
@@ -684,8 +735,12 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 // panel workspace P (n x nb, leading dimension nb, rows indexed globally).
 template <typename T>
 static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* winv, T* P, int64_t ldp, int32_t* info, hipStream_t st,
-                        int gflags, hipEvent_t first_diag = nullptr)
+                        int gflags, hipEvent_t first_diag = nullptr, hipStream_t diag_st = nullptr, hipEvent_t ev_diag = nullptr, hipEvent_t ev_gemm = nullptr)
 {
+	// diag_st != nullptr ("reserved" mode): the 128 x 128 diagonal-block kernel runs on its own stream, which is masked onto
+	// CUs the trailing update cannot use, with an event hand-over in each direction; the panel GEMMs stay on `st`.
+	const bool split = diag_st != nullptr && diag_st != st;
+#define FP_EV(x) do { if ((x) != hipSuccess) { set_error("potrf: event hand-over between the panel streams failed"); return -1003; } } while (0)
 	int rc;
 	for (int64_t c = k; c < k + kb; c += IB) {
 		const int64_t cb = (n - c < IB) ? (n - c) : IB;
@@ -695,12 +750,15 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 			rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 			if (rc) return rc;
 		}
+		hipStream_t ds = split ? diag_st : st;
+		if (split) { FP_EV(hipEventRecord(ev_gemm, st)); FP_EV(hipStreamWaitEvent(ds, ev_gemm, 0)); }
 		{
-			ProfScope ps(TAG_POTF2, (double)cb * cb * cb / 3.0, st);
-			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, st, (gflags & GEMM_BESIDE) != 0);
+			ProfScope ps(TAG_POTF2, (double)cb * cb * cb / 3.0, ds);
+			rc = potf2_trtri<T>(A + c * lda + c, lda, (int)cb, winv + (c / IB) * IB * IB, P + c * ldp + jj, ldp, info, (int)c, ds, !split && (gflags & GEMM_BESIDE) != 0);
 		}
 		if (rc) return rc;
-		if (c == k && first_diag && hipEventRecord(first_diag, st) != hipSuccess) { set_error("potrf: event record failed"); return -1003; }
+		if (c == k && first_diag && hipEventRecord(first_diag, ds) != hipSuccess) { set_error("potrf: event record failed"); return -1003; }
+		if (split) { FP_EV(hipEventRecord(ev_diag, ds)); FP_EV(hipStreamWaitEvent(st, ev_diag, 0)); }
 		if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
 			ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
 			rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
@@ -708,6 +766,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 			if (rc) return rc;
 		}
 	}
+#undef FP_EV
 	return 0;
 }
 
@@ -742,41 +801,59 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 	rc = factor_panel<T>(n, 0, wk, A, lda, winv, Pbuf[0], ldp, info, st, gflags);
 	if (rc) return rc;
 	int cur = 0;
+	// U: the stream the trailing updates run on -- the caller's, or (reserved mode) the one masked off one CU per XCD.  A
+	// change of mode orders the two streams through ev_mode; the caller's stream waits for the last update at the end.
+	hipStream_t U = st;
+	auto switch_to = [&](hipStream_t nu) -> int {
+		if (nu == U) return 0;
+		HIPCHK(hipEventRecord(la->ev_mode, U));
+		HIPCHK(hipStreamWaitEvent(nu, la->ev_mode, 0));
+		U = nu;
+		return 0;
+	};
 	for (int64_t k = 0; k + wk < n;) {
 		const int64_t r = k + wk;                                   // first row/column of the trailing matrix
 		const int64_t nkb = width(n - r);                           // width of the next panel
 		T* Pk = Pbuf[cur];
+		// Reserved mode: beside the real update the diagonal-block kernel is PLACED quickly but RUNS four to five times
+		// slower (in-kernel stamps, tools/potf2_stamps.py: 245-300 us against 58 us alone, every phase of it stretched alike),
+		// and it is the longest link of a chain that mid-size trailing matrices cannot hide.  With the update kept off one CU
+		// per XCD (3 % of the chip) that kernel runs alone on a reserved CU at its stand-alone speed.
+		const bool reserve = la->upd && (n - r) <= g_potrf_reserve_below && (n - r) >= g_potrf_reserve_above && !(gflags & GEMM_BESIDE);
+		rc = switch_to(reserve ? la->upd : st);
+		if (rc) return rc;
 		{   // next panel's block column (all rows below r)
-			ProfScope ps(TAG_SYRK, 2.0 * (double)(n - r) * (double)nkb * (double)wk - (double)nkb * (double)nkb * (double)wk, st);
-			rc = gemm_nt<T>(n - r, nkb, wk, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, st);
+			ProfScope ps(TAG_SYRK, 2.0 * (double)(n - r) * (double)nkb * (double)wk - (double)nkb * (double)nkb * (double)wk, U);
+			rc = gemm_nt<T>(n - r, nkb, wk, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, U);
 			if (rc) return rc;
 		}
-		HIPCHK(hipEventRecord(la->col_ready, st));
+		HIPCHK(hipEventRecord(la->col_ready, U));
 		HIPCHK(hipStreamWaitEvent(side, la->col_ready, 0));
 		// A short trailing update cannot hide the panel chain, and the chain's first kernel -- one workgroup that needs
-		// 83 KiB of LDS -- waits ~200 us for a CU slot once the update's workgroups have flooded the chip (kernel trace,
+		// 83 KiB of LDS -- is slowed down by the update's workgroups once they have flooded the chip (kernel trace,
 		// tools/potrf_only.py).  Below the threshold the update therefore starts only after that kernel has run.
-		const bool diag_first = (n - r) <= g_potrf_diag_first_below;
+		const bool diag_first = !reserve && (n - r) <= g_potrf_diag_first_below;
 		const int pflags = gflags | ((n - r - nkb) >= g_potrf_beside_min ? GEMM_BESIDE : 0);
-		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, pflags, diag_first ? la->trail_done : nullptr);
+		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, pflags, diag_first ? la->trail_done : nullptr,
+		                     reserve ? la->diag : nullptr, la->ev_diag, la->ev_gemm);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(la->panel_done, side));
-		if (diag_first) HIPCHK(hipStreamWaitEvent(st, la->trail_done, 0));
+		if (diag_first) HIPCHK(hipStreamWaitEvent(U, la->trail_done, 0));
 		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
 			const int64_t r2 = r + nkb;
-			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, st);      // lower triangle: m^2 k
-			rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, st);
+			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, U);      // lower triangle: m^2 k
+			rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, U);
 			if (rc) return rc;
 		}
-		HIPCHK(hipStreamWaitEvent(st, la->panel_done, 0));
+		HIPCHK(hipStreamWaitEvent(U, la->panel_done, 0));
 		// the side stream may not start overwriting workspace `cur` (panel k+2) before this
 		// trailing update has finished reading it: it waits on the next col_ready, which is
-		// recorded on `st` after this update -- stream order gives that for free.
+		// recorded on `U` after this update -- stream order (and ev_mode across a change of mode) gives that.
 		cur ^= 1;
 		k = r;
 		wk = nkb;
 	}
-	return 0;
+	return switch_to(st);
 }
 
 template int potf2_trtri<double>(double*, int64_t, int, double*, double*, int64_t, int32_t*, int, hipStream_t, bool);

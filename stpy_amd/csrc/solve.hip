@@ -132,6 +132,9 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 	// rows its lower levels have too few tiles per product and the panel forms below, which overlap the small kernels with
 	// a large product on a second stream (and split K), stay ahead (n = 65536, M = 1024: 97 vs 107 ms).
 	// (not for the triangular right-hand side of the inverse: value + gradient at N = 32768 0.615 s with the sweep, 0.677 s recursive)
+	// (tried and dropped: slabs of 1024 right-hand-side rows, each running this recursion on a stream of its own, to fill the chip
+	// in the deep levels whose products have few tiles.  One process, tools/trsm_sweep.py: n = 16 384, M = 4096 25.0 ms on one
+	// stream, 35.4 ms with two slabs, 42.6 ms with four; the same ordering at every size up to n = 65 536.)
 	if (g_trsm_right_looking >= 3 || (g_trsm_right_looking == 0 && m >= 2048 && !upper_rhs))
 		return trsm_recursive<T>(m, n, 0, n, L, ldl, winv, B, ldb, st, upper_rhs, g_trsm_right_looking >= 3 ? (int64_t)IB << (g_trsm_right_looking - 3) : 2 * IB, gflags);
 	if (g_trsm_right_looking == 1 || !work || (n < 32768 && g_trsm_right_looking != 2)) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs, gflags);

@@ -28,7 +28,7 @@ def main():
 		il = torch.full((d,), 0.25, dtype=torch.float64, device=dev)
 		K = torch.empty(n, n, dtype=torch.float64, device=dev)
 		winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device=dev)
-		work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), dtype=torch.uint8, device=dev)
+		work = torch.empty(max(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), 2 * n * 1024 * 8), dtype=torch.uint8, device=dev)          # (widest panel any policy picks)
 		info = torch.zeros(1, dtype=torch.int32, device=dev)
 		ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, d)), dtype=torch.uint8, device=dev)
 

@@ -1,5 +1,5 @@
-"""stpy_trsm_right_lt over a grid of (n, m) for the block-solve algorithms (stpy_tune key 5), one process.
-usage: python tools/trsm_sweep.py [key5 values, default 0,4]"""
+"""stpy_trsm_right_lt over a grid of (n, m) for the values of one stpy_tune key (default 5: the block-solve algorithm), one process.
+usage: python tools/trsm_sweep.py [values, default 0,4] [key, default 5] [f64only]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -7,6 +7,9 @@ from stpy_amd import _lib as L
 lib = L.load()
 dev = torch.device("cuda:0")
 vals = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "4"])]
+KEY = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+KEY_DEFAULT = int(lib.stpy_tune_get(KEY))
+F64ONLY = len(sys.argv) > 3
 
 def factor(n, dtype):
 	code = L.dtype_code(dtype)
@@ -22,26 +25,26 @@ def factor(n, dtype):
 	assert int(info.item()) == 0
 	return K, winv
 
-for dtype in (torch.float64, torch.float32):
+for dtype in ((torch.float64,) if F64ONLY else (torch.float64, torch.float32)):
 	code = L.dtype_code(dtype)
 	for n in (4096, 8192, 16384, 32768, 65536):
 		if dtype == torch.float32 and n not in (16384, 65536):
 			continue
 		K, winv = factor(n, dtype)
-		for m in (256, 1024, 4096, 10112):
+		for m in ((2048, 4096, 10112) if F64ONLY else (256, 1024, 4096, 10112)):
 			B = torch.rand(m, n, dtype=dtype, device=dev)
 			X = torch.empty_like(B)
 			res, outs = {}, {}
 			for rnd in range(3):
 				for v in vals:
-					lib.stpy_tune(5, v)
+					lib.stpy_tune(KEY, v)
 					tw = torch.empty(int(lib.stpy_trsm_workspace_bytes(code, m, n, 0)), dtype=torch.uint8, device=dev)
 					X.copy_(B); torch.cuda.synchronize(); t0 = time.perf_counter()
 					L.check(lib.stpy_trsm_right_lt(code, m, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(X), n, 0, 0, L.ptr(tw) if tw.numel() else None, tw.numel(), L.stream_ptr()), "trsm")
 					torch.cuda.synchronize(); res.setdefault(v, []).append(time.perf_counter() - t0)
 					if rnd == 0:
 						outs[v] = X[:64].clone()
-			lib.stpy_tune(5, 0)
+			lib.stpy_tune(KEY, KEY_DEFAULT)
 			diff = max(float((outs[v] - outs[vals[0]]).norm() / outs[vals[0]].norm()) for v in vals)
 			print("%s n %6d m %6d: " % ("f64" if dtype == torch.float64 else "f32", n, m) + "  ".join("[%d] %8.2f ms %5.1f TF" % (v, min(res[v]) * 1e3, float(n) * n * m / min(res[v]) / 1e12) for v in vals) + "   rel diff %.1e" % diff, flush=True)
 			del B, X
