@@ -33,9 +33,6 @@ struct LookAhead {
 	hipStream_t upd = nullptr, diag = nullptr;
 	hipEvent_t ev_diag = nullptr, ev_gemm = nullptr, ev_mode = nullptr;
 };
-	hipEvent_t slab_done[MAX_SLABS - 1] = {nullptr, nullptr, nullptr};
-	hipEvent_t fork = nullptr;
-};
 int lookahead_acquire(hipStream_t caller, LookAhead** out);
 
 // per-call behaviour flags of stpy_potrf / stpy_trsm_right_lt (include/stpy_hip.h: STPY_FLAG_*), passed down to the GEMM launcher
