@@ -275,6 +275,107 @@ void rff_stream_f32_kernel(const float* __restrict__ x, int64_t ldx, const float
 	}
 }
 
+// ---- the same streaming kernel with the MFMA operands SWAPPED (W tile as the "row" operand, x rows as the "column" operand):
+// the accumulator of tile (tn, tm) then holds, in lane (r16, kq), the four CONSECUTIVE features tn*16 + 4 kq .. + 3 of sample
+// tm*16 + r16 -- exactly one 16-byte store per MFMA tile, straight from the registers.  No LDS patch, no ds_write per element,
+// no ds_read / wait before the stores: the trig of tile j-1 is converted in place and stored between the MFMAs of tile j.
+// A store instruction writes 16 segments of 64 bytes; the other half of each 128-byte line follows from the same wave's next
+// tn tile.  (stpy_tune key 9 = 3; measured against the LDS-patch form in one process by tools/rff_routes.py.)
+__global__ __launch_bounds__(256, 2)
+void rff_stream_direct_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                                  float* __restrict__ out, int64_t ldo, int row_blocks, int cols_per_part, int half,
+                                  const float* __restrict__ bias, float scale, int exp)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+	const int r16 = lane & 15, kq = lane >> 4;
+	constexpr float INV_2PI = 0.15915494309189535f;
+	const int part = blockIdx.x & 7;
+	const int tiles = cols_per_part / 64;
+	const int colp = part * cols_per_part;
+	const unsigned w_lane = (unsigned)r16 * (unsigned)ldw + 4u * kq;
+	const unsigned o_lane = (unsigned)r16 * (unsigned)ldo + 4u * kq;            // sample r16 of a 16-row tile, features 4 kq ..
+
+	for (int rb = blockIdx.x >> 3; rb < row_blocks; rb += gridDim.x >> 3) {
+		const int64_t row0 = (int64_t)rb * 128 + wm * 64;
+		v4f a[4][4];
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int g = 0; g < 4; ++g) a[tm][g] = *(const v4f*)(x + (row0 + tm * 16 + r16) * ldx + 16 * g + 4 * kq) * INV_2PI;
+
+		auto load_b = [&](v4f (&b)[2][4], int j) {
+			if ((exp & 4) && j > 1) return;
+			const float* const wb = W + (int64_t)(colp + (2 * j + wn) * 32) * ldw;
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+				for (int g = 0; g < 4; ++g) b[tn][g] = *(const v4f*)((wb + (int64_t)(tn * 16) * ldw + 16 * g) + w_lane);
+		};
+		// MFMAs of tile j into `acc` (indexed [tn][tm]); between them the previous tile's `res` is turned into outputs in place and
+		// stored: one (tn, tm) tile = 4 fract + 4 cos + 4 mul + 1 store, spread over the 16 steps of 8 MFMAs
+		auto tile = [&](auto have_tag, v4f (&acc)[2][4], const v4f (&b)[2][4], v4f (&res)[2][4], int j) {
+			constexpr bool HAVE = decltype(have_tag)::value;
+			v4f offv[2];
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn) {
+				const int col = colp + (2 * j + wn) * 32 + tn * 16 + 4 * kq;
+				if (bias) offv[tn] = *(const v4f*)(bias + col) * INV_2PI;
+				else {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) offv[tn][i] = (col + i < half) ? 0.f : -0.25f;
+				}
+			}
+			float* const ob = out + row0 * ldo + (colp + (2 * (j - 1) + wn) * 32);      // previous tile's output columns (uniform)
+#pragma unroll
+			for (int g = 0; g < 4; ++g)
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int step = g * 4 + c;
+#pragma unroll
+					for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+						for (int tm = 0; tm < 4; ++tm)
+							acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[tn][g][c], a[tm][g][c], step == 0 ? offv[tn] : acc[tn][tm], 0, 0, 0);
+					if constexpr (HAVE) {
+						if ((step & 1) == 0) {                 // eight (tn, tm) tiles over sixteen steps: convert on even steps, store on odd ones
+							const int t = step >> 1, tn = t >> 2, tm = t & 3;
+#pragma unroll
+							for (int i = 0; i < 4; ++i) res[tn][tm][i] = scale * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(res[tn][tm][i]));
+						} else if (!((exp & 1) && scale != 12345.f)) {
+							const int t = step >> 1, tn = t >> 2, tm = t & 3;
+							__builtin_nontemporal_store(res[tn][tm], (v4f*)((ob + (int64_t)(tm * 16) * ldo + tn * 16) + o_lane));
+						}
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+		};
+		auto finish = [&](v4f (&res)[2][4], int j) {           // last tile of the sweep
+			if ((exp & 1) && scale != 12345.f) return;
+			float* const ob = out + row0 * ldo + (colp + (2 * j + wn) * 32);
+#pragma unroll
+			for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+				for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) res[tn][tm][i] = scale * __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(res[tn][tm][i]));
+					__builtin_nontemporal_store(res[tn][tm], (v4f*)((ob + (int64_t)(tm * 16) * ldo + tn * 16) + o_lane));
+				}
+		};
+		v4f b0[2][4], b1[2][4], acc0[2][4], acc1[2][4];
+		load_b(b0, 0);
+		for (int j = 0; j < tiles; j += 2) {
+			load_b(b1, j + 1);
+			if (j == 0) tile(std::false_type{}, acc0, b0, acc1, j);
+			else tile(std::true_type{}, acc0, b0, acc1, j);             // tile j; stores tile j-1
+			load_b(b0, j + 2 < tiles ? j + 2 : j);
+			tile(std::true_type{}, acc1, b1, acc0, j + 1);              // tile j+1; stores tile j
+		}
+		finish(acc1, tiles - 1);
+	}
+}
+
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
               const T* bias, const T* feat_scale, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
@@ -293,7 +394,8 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 		const int row_blocks = (int)(n / 128);
 		int wgs = 512;                                                   // two per CU; a multiple of eight (one column part per XCD)
 		if (wgs > 8 * row_blocks) wgs = 8 * row_blocks;
-		hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
+		if (g_rff_tile == 3) hipLaunchKernelGGL(rff_stream_direct_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
+		else hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
 		return check_launch("rff_stream_f32");
 	}
 	if (!feat_scale && g_rff_tile && !transposed && (d == 32 || d == 64) && n % 128 == 0 && m % 64 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
