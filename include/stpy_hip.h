@@ -22,7 +22,8 @@
  *       * per (device, caller stream): one high-priority side stream + three events, created on the first
  *         stpy_potrf / stpy_trsm_right_lt call on that stream and kept for the life of the process (the panel
  *         look-ahead).  Host threads that drive DIFFERENT streams may call concurrently; calls that share a
- *         stream must be issued by one thread at a time (they are ordered by the stream, like any HIP work);
+ *         stream must be issued by one thread at a time (they are ordered by the stream, like any HIP work); with them 64 bytes
+ *         of device memory (the ticket / counter words of the one-launch vector solve), the library's only allocation;
  *       * the launch profiler's record table (stpy_profile_*), guarded by a mutex, off by default;
  *       * the stpy_tune A/B switches: process-wide integers read at launch time.  They exist for tools/ timing
  *         experiments, are never written by the shipped host code, and must not be changed while another
@@ -240,7 +241,8 @@ void stpy_profile_enable(int enable);
  *    trailing update has at least this many rows (0: always) · 11 the four-wave / 64-VGPR diagonal-block kernel in that mode (0) ·
  * 12 / 13 potrf updates trailing matrices of at most / at least this many rows on a stream masked off one CU per XCD and runs
  *    the diagonal-block kernel on those reserved CUs (0 = never / 2048) · 14 / 15 adaptive panel width of potrf: 256 columns while
- *    at most this many rows are left, 512 up to the second value, 1024 beyond (2048 / 16384) */
+ *    at most this many rows are left, 512 up to the second value, 1024 beyond (2048 / 16384) ·
+ * 16 the vector solves as one dataflow launch for n a multiple of 128 (1; 0: the chain of per-block launches) */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */
 int stpy_tune_get(int key);

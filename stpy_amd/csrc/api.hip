@@ -354,6 +354,7 @@ void stpy_tune(int key, int value)
 	if (key == 13) g_potrf_reserve_above = value;
 	if (key == 14) g_potrf_nb256_upto = value;
 	if (key == 15) g_potrf_nb512_upto = value;
+	if (key == 16) g_trsv_flow = value;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
@@ -376,6 +377,7 @@ int stpy_tune_get(int key)
 	case 13: return g_potrf_reserve_above;
 	case 14: return g_potrf_nb256_upto;
 	case 15: return g_potrf_nb512_upto;
+	case 16: return g_trsv_flow;
 	default: return -1;
 	}
 }

@@ -32,6 +32,8 @@ struct LookAhead {
 	// "reserved" mode of potrf: update stream masked off one CU per XCD, diagonal-block stream masked onto those CUs
 	hipStream_t upd = nullptr, diag = nullptr;
 	hipEvent_t ev_diag = nullptr, ev_gemm = nullptr, ev_mode = nullptr;
+	// 16 bytes of device memory: ticket / published-count / error words of the one-launch vector solve (solve.hip)
+	void* trsv_sync = nullptr;
 };
 int lookahead_acquire(hipStream_t caller, LookAhead** out);
 
@@ -97,7 +99,7 @@ template <typename T>
 int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false, T* work = nullptr, int gflags = 0);
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
-extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking;
+extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking, g_trsv_flow;
 extern int g_potrf_diag_first_below, g_potrf_beside_min, g_potrf_reserve_below, g_potrf_reserve_above;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);

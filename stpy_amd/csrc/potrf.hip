@@ -725,6 +725,7 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 			la->upd = la->diag = nullptr;
 		}
 	}
+	if (hipMalloc(&la->trsv_sync, 64) != hipSuccess) { (void)hipGetLastError(); la->trsv_sync = nullptr; }          // (the vector solves then take the step kernels)
 	g_la_map[key] = la;
 	*out = la;
 	return 0;

@@ -1,6 +1,8 @@
 // solve.hip -- everything downstream of the factor: B L^-T for blocks of right-hand sides (MFMA
 // GEMMs with the cached inverse diagonal blocks), L^-1 y / L^-T y for single vectors (HBM-bound
 // streaming of L), the fused prediction epilogue and the log-marginal reductions.
+#include <atomic>
+
 #include "common.h"
 
 namespace stpy {
@@ -333,10 +335,209 @@ void trsv_bwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W
 	if (hf == 0 && live) y[j] = yold - (s + red[jl]);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same solves as ONE launch (n a multiple of 128): a dataflow over the 128-blocks.  The step kernels above are a chain
+// of n/128 dependent launches, ~12 us each: 1.5 ms per solve at n = 16 384 (3 ms of BASELINE config 2's 61 ms go to the two
+// of them), 6 ms at n = 65 536, for 0.27 / 4.3 ms of HBM streaming.  Here workgroup k (k = its START order: a ticket taken
+// from an atomic counter, so every lower ticket is resident or finished and waiting on it cannot deadlock) owns block
+// i = k (forward) or nblk-1-k (backward); it streams its blocks of L once, two blocks ahead in registers (one wave per SIMD:
+// 512 VGPRs), multiplies each with the solved block t_j as soon as that is published, and publishes t_i = inverse(L_ii) y_i.
+// Hand-off of the 1 KiB t blocks: write-through (agent-scope relaxed atomic = sc1) stores, every storing wave drains its
+// stores, workgroup barrier, ONE lane publishes the monotonic counter with an sc1 store; consumers poll the counter from
+// one lane (sc1 load, s_sleep, bounded), barrier, and read t_j with sc1 loads only (MI355X_MICROARCH.md, "Valid forms":
+// sc1 stores + drained + flag on one side, sc1 poll + barrier + sc1 loads on the other; one workgroup per CU).
+// ------------------------------------------------------------------------------------------
+struct TrsvSync { unsigned ticket, count, error, pad; };
+int g_trsv_flow = 1;           // stpy_tune key 16: 0 = always the chain of step kernels
+
+template <typename T>
+__device__ __forceinline__ T load_sc1(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void store_sc1(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename T, bool BACK>
+__global__ __launch_bounds__(256, 1)
+void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W, const T* __restrict__ y, T* out, int nblk, TrsvSync* sy)
+{
+	__shared__ int s_k, s_ready;
+	__shared__ T yc[IB];
+	__shared__ T red[16][IB + 1];
+	const int tid = threadIdx.x;
+	if (tid == 0) s_k = (int)atomicAdd(&sy->ticket, 1u);
+	__syncthreads();
+	const int k = s_k;
+	if (k >= nblk) return;
+	const int i = BACK ? nblk - 1 - k : k;
+	// thread -> 8 consecutive columns (c8) of the rows ps*16 + rr, ps = 0..7: every row segment of a 128 x 128 block is one
+	// coalesced 1 KiB read of 16 lanes
+	const int c8 = tid & 15, rr = tid >> 4;
+	typedef T blk[8][8];
+	auto load_block = [&](T (&v)[8][8], const T* base) {
+#pragma unroll
+		for (int ps = 0; ps < 8; ++ps) {
+			const T* p = base + (int64_t)(ps * 16 + rr) * ldl + c8 * 8;
+#pragma unroll
+			for (int e = 0; e < 8; ++e) v[ps][e] = p[e];
+		}
+	};
+	T wv[8][8];          // inverse(L_ii), row-major with leading dimension 128
+#pragma unroll
+	for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+		for (int e = 0; e < 8; ++e) wv[ps][e] = W[(int64_t)i * IB * IB + (ps * 16 + rr) * IB + c8 * 8 + e];
+
+	// right-hand side of this block, fetched now (its latency would otherwise sit on the chain's critical path)
+	const T y_early = BACK ? (tid < IB ? y[(int64_t)i * IB + tid] : T(0)) : T(0);
+	T y_rows[8];
+#pragma unroll
+	for (int ps = 0; ps < 8; ++ps) y_rows[ps] = BACK ? T(0) : y[(int64_t)i * IB + ps * 16 + rr];
+	int ready = 0;
+	auto wait_for = [&](int j) {          // returns once block with ticket j has been published (all threads)
+		if (tid == 0) {
+			// (a workgroup far behind the front sleeps longer between polls: a hundred workgroups hammering one word slow the
+			// publisher's own write-through stores down)
+			unsigned c = load_sc1(&sy->count);
+			for (int spin = 0; (int)c <= j && spin < 1000000; ++spin) {
+				const int dist = k - (int)c;
+				if (dist > 8) __builtin_amdgcn_s_sleep(127); else if (dist > 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
+				c = load_sc1(&sy->count);
+			}
+			if ((int)c <= j) { atomicExch(&sy->error, 1u); c = (unsigned)nblk; }          // give up rather than hang (results are then wrong)
+			s_ready = (int)c;
+		}
+		__syncthreads();
+		const int r = s_ready;
+		__syncthreads();
+		return r;
+	};
+	T acc[8];
+#pragma unroll
+	for (int e = 0; e < 8; ++e) acc[e] = T(0);
+	// forward: acc[ps] = partial dot of row ps*16+rr over this thread's 8 columns; backward: acc[e] = partial sum of column
+	// c8*8+e over this thread's 8 rows
+	const int nprev = k;                  // number of already-solved blocks this one depends on (tickets 0..k-1)
+	// two register images of a block, used alternately (the loop is unrolled by two so that both are indexed statically:
+	// a run-time index sends the arrays to scratch)
+	T lv0[8][8], lv1[8][8];
+	auto block_of = [&](int q) {          // address of the block that pairs this workgroup's block with ticket q's
+		const int j = BACK ? nblk - 1 - q : q;
+		return BACK ? L + (int64_t)j * IB * ldl + (int64_t)i * IB : L + (int64_t)i * IB * ldl + (int64_t)j * IB;
+	};
+	auto consume = [&](const T (&lv)[8][8], int q) {
+		if (q >= ready) ready = wait_for(q);
+		const int j = BACK ? nblk - 1 - q : q;
+		const T* tj = out + (int64_t)j * IB;
+		T tv[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) tv[u] = load_sc1(tj + (BACK ? u * 16 + rr : c8 * 8 + u));
+		if (!BACK) {
+#pragma unroll
+			for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+				for (int e = 0; e < 8; ++e) acc[ps] += lv[ps][e] * tv[e];
+		} else {
+#pragma unroll
+			for (int ps = 0; ps < 8; ++ps)
+#pragma unroll
+				for (int e = 0; e < 8; ++e) acc[e] += lv[ps][e] * tv[ps];
+		}
+	};
+	if (nprev > 0) load_block(lv0, block_of(0));
+	for (int q = 0; q < nprev; q += 2) {
+		if (q + 1 < nprev) load_block(lv1, block_of(q + 1));
+		consume(lv0, q);
+		if (q + 1 < nprev) {
+			if (q + 2 < nprev) load_block(lv0, block_of(q + 2));
+			consume(lv1, q + 1);
+		}
+	}
+	// ---- y_i = rhs_i - (accumulated products)
+	if (!BACK) {
+#pragma unroll
+		for (int ps = 0; ps < 8; ++ps) {
+			T sum = acc[ps];
+			sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+			if (c8 == 0) yc[ps * 16 + rr] = y_rows[ps] - sum;
+		}
+	} else {
+#pragma unroll
+		for (int e = 0; e < 8; ++e) red[rr][c8 * 8 + e] = acc[e];
+		__syncthreads();
+		if (tid < IB) {
+			T sum = T(0);
+#pragma unroll
+			for (int r = 0; r < 16; ++r) sum += red[r][tid];
+			yc[tid] = y_early - sum;
+		}
+	}
+	__syncthreads();
+	// ---- t_i = inverse(L_ii) y_i (forward) or inverse(L_ii)^T y_i (backward), published write-through
+	T* ti = out + (int64_t)i * IB;
+	if (!BACK) {
+		T yv[8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) yv[e] = yc[c8 * 8 + e];
+#pragma unroll
+		for (int ps = 0; ps < 8; ++ps) {
+			T sum = T(0);
+#pragma unroll
+			for (int e = 0; e < 8; ++e) sum += wv[ps][e] * yv[e];
+			sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+			if (c8 == 0) store_sc1(ti + ps * 16 + rr, sum);
+		}
+	} else {
+		T part[8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) part[e] = T(0);
+#pragma unroll
+		for (int ps = 0; ps < 8; ++ps) {
+			const T yr = yc[ps * 16 + rr];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) part[e] += wv[ps][e] * yr;
+		}
+		__syncthreads();          // (red is reused)
+#pragma unroll
+		for (int e = 0; e < 8; ++e) red[rr][c8 * 8 + e] = part[e];
+		__syncthreads();
+		if (tid < IB) {
+			T sum = T(0);
+#pragma unroll
+			for (int r = 0; r < 16; ++r) sum += red[r][tid];
+			store_sc1(ti + tid, sum);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores ...
+	__syncthreads();                                           // ... before ONE lane publishes the counter
+	if (tid == 0) store_sc1(&sy->count, (unsigned)(k + 1));
+}
+
 template <typename T>
 int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int trans, hipStream_t st)
 {
 	if (n > INT32_MAX) { set_error("trsv: n exceeds int32"); return -2; }
+	if (g_trsv_flow && n % IB == 0 && n >= 4 * IB && ldl % (16 / (int)sizeof(T)) == 0) {
+		LookAhead* la = nullptr;
+		int rc = lookahead_acquire(st, &la);
+		if (rc) return rc;
+		if (la->trsv_sync) {
+			if (hipMemsetAsync(la->trsv_sync, 0, sizeof(TrsvSync), st) != hipSuccess) { set_error("trsv: hipMemsetAsync failed"); return -1004; }
+			const int nblk = (int)(n / IB);
+			// 84 KiB of (unused) dynamic LDS: ONE workgroup per CU, the configuration the sc1 hand-off form is measured for -- and
+			// what the kernel wants anyway (one wave per SIMD, three register images of a block)
+			constexpr int PAD_LDS = 84 * 1024;
+			static std::atomic<bool> attr_set[2];
+			const int which = sizeof(T) == 8 ? 0 : 1;
+			if (!attr_set[which].load(std::memory_order_acquire)) {
+				hipError_t e = hipFuncSetAttribute((const void*)trsv_flow_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PAD_LDS);
+				if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trsv_flow_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PAD_LDS);
+				if (e != hipSuccess) { set_error("trsv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
+				attr_set[which].store(true, std::memory_order_release);
+			}
+			if (!trans) hipLaunchKernelGGL((trsv_flow_kernel<T, false>), dim3((unsigned)nblk), dim3(256), PAD_LDS, st, L, ldl, winv, (const T*)y, out, nblk, (TrsvSync*)la->trsv_sync);
+			else hipLaunchKernelGGL((trsv_flow_kernel<T, true>), dim3((unsigned)nblk), dim3(256), PAD_LDS, st, L, ldl, winv, (const T*)y, out, nblk, (TrsvSync*)la->trsv_sync);
+			return check_launch("trsv (flow)");
+		}
+	}
 	if (!trans) {
 		for (int64_t c = 0; c < n; c += IB) {
 			const int cb = (int)((n - c < IB) ? (n - c) : IB);

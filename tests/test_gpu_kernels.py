@@ -758,3 +758,35 @@ def test_potrf_and_trsm_beside_update(L, dtype, tol, n, nb):
 		Kb[700, 700] = -1.0
 		_, _, infob = run_potrf(L, Kb, nb, dtype, flags=L.FLAG_BESIDE_UPDATE)
 		assert infob == 701
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-4)])
+@pytest.mark.parametrize("n", [512, 1024, 4096, 8192 + 128])
+def test_trsv_one_launch_dataflow(L, dtype, tol, n):
+	"""n a multiple of 128 (>= 512): both vector solves run as ONE launch each -- a dataflow over the 128-blocks with
+	write-through hand-off of the solved blocks (stpy_tune key 16 = 1, the default) -- and agree with scipy and, to rounding,
+	with the chain of per-block launches (key 16 = 0); repeated calls reuse the 64-byte sync area correctly."""
+	lib = L.load()
+	rng = np.random.RandomState(n)
+	K = spd(rng, n)
+	Ld, winv, info = run_potrf(L, K, 0, dtype)
+	assert info == 0
+	Lref = np.linalg.cholesky(K)
+	code = L.dtype_code(dtype)
+	y = rng.normal(size=n)
+	zref = sla.solve_triangular(Lref, y, lower=True)
+	aref = sla.solve_triangular(Lref.T, zref, lower=False)
+	outs = {}
+	try:
+		for mode in (1, 0, 1):
+			lib.stpy_tune(16, mode)
+			yd = dev(y, dtype)
+			zd, ad = torch.full((n,), float("nan"), dtype=dtype, device="cuda:0"), torch.full((n,), float("nan"), dtype=dtype, device="cuda:0")
+			L.check(lib.stpy_trsv(code, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
+			zs = zd.clone()
+			L.check(lib.stpy_trsv(code, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(zs), L.ptr(ad), 1, L.stream_ptr()), "trsv")
+			outs[mode] = (zd.cpu().numpy().astype(np.float64), ad.cpu().numpy().astype(np.float64))
+			assert rel_err(outs[mode][0], zref) < tol and rel_err(outs[mode][1], aref) < tol * 10
+	finally:
+		lib.stpy_tune(16, 1)
+	assert rel_err(outs[1][0], outs[0][0]) < tol and rel_err(outs[1][1], outs[0][1]) < tol * 10
