@@ -154,7 +154,7 @@ int64_t stpy_trsm_workspace_bytes(int dtype, int64_t m, int64_t n, int nb)
 {
 	if (m <= 0 || n <= 0) return 0;
 	if (nb <= 0) nb = trsm_auto_nb(m);
-	if (g_trsm_right_looking >= 3 || (g_trsm_right_looking == 0 && m >= 2048)) return 0;      // recursive form: no workspace
+	if (trsm_is_recursive(dtype == STPY_F32 ? 4 : 8, m, false)) return 0;      // recursive form: no workspace
 	if (n <= nb || (n < 32768 && g_trsm_right_looking != 2)) return 0;       // the right-looking sweep serves these sizes and needs none
 	return (int64_t)TRSM_MAX_PASSES * m * nb * (int64_t)(dtype == STPY_F32 ? 4 : 8);
 }
@@ -355,6 +355,7 @@ void stpy_tune(int key, int value)
 	if (key == 14) g_potrf_nb256_upto = value;
 	if (key == 15) g_potrf_nb512_upto = value;
 	if (key == 16) g_trsv_flow = value;
+	if (key == 17) g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0;
 }
 
 /* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
@@ -378,6 +379,7 @@ int stpy_tune_get(int key)
 	case 14: return g_potrf_nb256_upto;
 	case 15: return g_potrf_nb512_upto;
 	case 16: return g_trsv_flow;
+	case 17: return g_trsm_strip;
 	default: return -1;
 	}
 }

@@ -99,7 +99,14 @@ template <typename T>
 int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false, T* work = nullptr, int gflags = 0);
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
-extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking, g_trsv_flow;
+extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking, g_trsv_flow, g_trsm_strip;
+// which form stpy_trsm_right_lt takes (shared by the solve and by stpy_trsm_workspace_bytes): the recursive one needs no workspace
+inline bool trsm_is_recursive(size_t elem, int64_t m, bool upper_rhs)
+{
+	if (g_trsm_right_looking >= 3) return true;
+	if (g_trsm_right_looking != 0 || upper_rhs) return false;
+	return m >= 2048 || (elem == 8 && g_trsm_strip > 0 && m % 16 == 0);
+}
 extern int g_potrf_diag_first_below, g_potrf_beside_min, g_potrf_reserve_below, g_potrf_reserve_above;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);

@@ -2,6 +2,7 @@
 // GEMMs with the cached inverse diagonal blocks), L^-1 y / L^-T y for single vectors (HBM-bound
 // streaming of L), the fused prediction epilogue and the log-marginal reductions.
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 
@@ -36,6 +37,120 @@ static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, 
 		if (rc) return rc;
 	}
 	return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Leaf of the recursive block solve as ONE launch: X[:, c0 : c0 + 128 NBLK] <- X L_D^-T for the NBLK x NBLK diagonal block
+// D of L (fp64, rows a multiple of 16).  Through the recursion such a leaf is 3 launches per 256 columns plus the small
+// products of the levels above it -- 32-128 tiles each on a chip with 512 workgroup slots: at n = 16 384, M = 4096 the levels
+// below 1024 columns take ~5 of 24 ms for 2 % of the flops.  Here a workgroup owns 16 rows for the whole leaf:
+//   * its 16 x (128 NBLK) strip lives in the MFMA accumulators (wave w: the 32-column quarter w of every 128-block);
+//   * block j: the strip's block (already carrying - sum_{i<j} X_i L_ji^T) goes through LDS to become the A operand of
+//     X_j = . W_j^T (W_j = inverse(L_jj), cached), X_j is stored, goes through LDS again and updates the later blocks
+//     acc_jj -= X_j L_jj,j^T;
+//   * the B operands (W_j, L_jj,j: 128 x 128, shared by every workgroup, L2-resident) are read straight into registers one
+//     K tile ahead -- no LDS staging, no barrier inside a product.
+// ------------------------------------------------------------------------------------------
+constexpr int TS_ROWS = 16, TS_LD = IB + 2;          // LDS row stride 130 doubles: 16 lanes reading 16 rows hit 16 different 4-bank groups
+template <int NBLK>
+__global__ __launch_bounds__(256)
+void trsm_strip_kernel(const double* __restrict__ L, int64_t ldl, const double* __restrict__ W, double* __restrict__ X, int64_t ldx, int c0)
+{
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	__shared__ __attribute__((aligned(16))) double tile[TS_ROWS * TS_LD];
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int r16 = lane & 15, g = lane >> 4;
+	const int64_t row0 = (int64_t)blockIdx.x * TS_ROWS;
+	double* const xs = X + row0 * ldx + c0;          // this workgroup's strip
+
+	// accumulators: acc[j][t] = rows (lane>>4) + 4 i, column 128 j + 32 wave + 16 t + r16
+	v4 acc[NBLK][2];
+#pragma unroll
+	for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+		for (int t = 0; t < 2; ++t)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) acc[j][t][i] = xs[(int64_t)(g + 4 * i) * ldx + 128 * j + 32 * wave + 16 * t + r16];
+
+	// C fragment -> LDS tile (16 x 128, K-contiguous rows): the A operand of the next product
+	auto to_tile = [&](const v4 (&c)[2]) {
+#pragma unroll
+		for (int t = 0; t < 2; ++t)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) tile[(g + 4 * i) * TS_LD + 32 * wave + 16 * t + r16] = c[t][i];
+	};
+	// out[t] (+|-)= tile (16 x 128) * Bblk[32 wave + 16 t + r16][0:128]^T ; Bblk row-major with leading dimension ldb
+	auto product = [&](auto sub_tag, v4 (&out)[2], const double* Bblk, int64_t ldb) {
+		constexpr bool SUBT = decltype(sub_tag)::value;
+		const double* brow0 = Bblk + (int64_t)(32 * wave + r16) * ldb + 2 * g * 2;          // chunk 2g of row (tile 0)
+		const double* brow1 = brow0 + 16 * ldb;
+		const double* arow = tile + r16 * TS_LD + 2 * g * 2;
+		d2 b0[2][2], b1[2][2];          // [tile][half] for K tile kt (b0) and kt + 1 (b1)
+		auto loadb = [&](d2 (&b)[2][2], int kt) {
+#pragma unroll
+			for (int h = 0; h < 2; ++h) { b[0][h] = *(const d2*)(brow0 + kt * 16 + 2 * h); b[1][h] = *(const d2*)(brow1 + kt * 16 + 2 * h); }
+		};
+		auto step = [&](const d2 (&b)[2][2], int kt) {
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const d2 a = *(const d2*)(arow + kt * 16 + 2 * h);
+#pragma unroll
+				for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+					for (int t = 0; t < 2; ++t) out[t] = SUBT ? MM::mms(a[s2], b[t][h][s2], out[t]) : MM::mma(a[s2], b[t][h][s2], out[t]);
+			}
+		};
+		loadb(b0, 0);
+#pragma unroll
+		for (int kt = 0; kt < 8; kt += 2) {
+			loadb(b1, kt + 1);
+			step(b0, kt);
+			if (kt + 2 < 8) loadb(b0, kt + 2);
+			step(b1, kt + 1);
+		}
+	};
+
+#pragma unroll
+	for (int j = 0; j < NBLK; ++j) {
+		to_tile(acc[j]);
+		__syncthreads();
+		v4 xj[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
+		product(std::false_type{}, xj, W + (int64_t)(c0 / IB + j) * IB * IB, IB);          // X_j = (.) inverse(L_jj)^T
+#pragma unroll
+		for (int t = 0; t < 2; ++t)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) xs[(int64_t)(g + 4 * i) * ldx + 128 * j + 32 * wave + 16 * t + r16] = xj[t][i];
+		if (j + 1 < NBLK) {
+			__syncthreads();                     // everybody has read the tile
+			to_tile(xj);
+			__syncthreads();
+#pragma unroll
+			for (int jj = j + 1; jj < NBLK; ++jj)
+				product(std::true_type{}, acc[jj], L + (int64_t)(c0 + 128 * jj) * ldl + c0 + 128 * j, ldl);          // acc_jj -= X_j L_jj,j^T
+			__syncthreads();
+		}
+	}
+}
+
+int g_trsm_strip = 1;            // stpy_tune key 17: leaf width of the recursive block solve handled by trsm_strip_kernel (0 = off; 512; 1024;
+                                 // 1 = by row count: 1024 while the m / 16 workgroups fit the chip at once (202 VGPRs: two per CU), 512 above)
+
+template <typename T>
+static int trsm_strip(int64_t m, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int64_t c0, int64_t w, hipStream_t st)
+{
+	if constexpr (sizeof(T) == 8) {
+		const dim3 grid((unsigned)(m / TS_ROWS)), block(256);
+		switch ((int)(w / IB)) {
+#define STPY_STRIP(NB) case NB: hipLaunchKernelGGL((trsm_strip_kernel<NB>), grid, block, 0, st, L, ldl, winv, B, ldb, (int)c0); break;
+			STPY_STRIP(1) STPY_STRIP(2) STPY_STRIP(3) STPY_STRIP(4) STPY_STRIP(5) STPY_STRIP(6) STPY_STRIP(7) STPY_STRIP(8)
+#undef STPY_STRIP
+			default: set_error("trsm strip leaf: width %lld", (long long)w); return -2;
+		}
+		return check_launch("trsm (strip leaf)");
+	}
+	return -1;
 }
 
 #define HIPCHK_S(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("trsm: %s failed: %s", #x, hipGetErrorString(e_)); return -1000 - (int)e_; } } while (0)
@@ -86,6 +201,12 @@ static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, con
 template <typename T>
 static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int64_t leaf, int gflags)
 {
+	const int64_t strip_w = g_trsm_strip == 1 ? (m <= 8192 ? 1024 : 512) : g_trsm_strip;
+	if (sizeof(T) == 8 && strip_w > 0 && w <= strip_w && w % IB == 0 && !upper_rhs && m % TS_ROWS == 0 && c0 + w <= n && ldl % 2 == 0 && ldb % 2 == 0 &&
+	    m / TS_ROWS < 65536 * (int64_t)32768 && (((uintptr_t)L | (uintptr_t)B | (uintptr_t)winv) & 15) == 0 && c0 < (1 << 30)) {
+		ProfScope ps(TAG_TRSM_GEMM, (double)m * (double)w * (double)w, st);
+		return trsm_strip<T>(m, L, ldl, winv, B, ldb, c0, w, st);
+	}
 	if (w <= leaf) return solve_panel<T>(m, n, c0, w, L, ldl, winv, B, ldb, st, upper_rhs, gflags);
 	int64_t h = IB;
 	while (h * 2 < w) h *= 2;                                 // largest power-of-two multiple of 128 below w
@@ -133,11 +254,14 @@ int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, 
 	// n = 16384, 83.9 -> 80.4 at 32768, 288 -> 284 at 65536; M = 10112: 705 -> 650 ms at 65536 = 66.9 TFLOP/s).  With fewer
 	// rows its lower levels have too few tiles per product and the panel forms below, which overlap the small kernels with
 	// a large product on a second stream (and split K), stay ahead (n = 65536, M = 1024: 97 vs 107 ms).
+	// Round 2: with the leaves of the recursion as one strip launch each (trsm_strip_kernel, fp64, rows a multiple of 16) the
+	// recursive form is ahead at every row count (tools/trsm_sweep.py 0,4 5 f64only 256,512,1024,1536: n = 16 384, M = 256
+	// 8.8 -> 6.4 ms, M = 1024 13.8 -> 10.5 ms; n = 65 536, M = 1024 91 -> 87 ms), so fp64 takes it whenever the strips apply.
 	// (not for the triangular right-hand side of the inverse: value + gradient at N = 32768 0.615 s with the sweep, 0.677 s recursive)
 	// (tried and dropped: slabs of 1024 right-hand-side rows, each running this recursion on a stream of its own, to fill the chip
 	// in the deep levels whose products have few tiles.  One process, tools/trsm_sweep.py: n = 16 384, M = 4096 25.0 ms on one
 	// stream, 35.4 ms with two slabs, 42.6 ms with four; the same ordering at every size up to n = 65 536.)
-	if (g_trsm_right_looking >= 3 || (g_trsm_right_looking == 0 && m >= 2048 && !upper_rhs))
+	if (trsm_is_recursive(sizeof(T), m, upper_rhs))
 		return trsm_recursive<T>(m, n, 0, n, L, ldl, winv, B, ldb, st, upper_rhs, g_trsm_right_looking >= 3 ? (int64_t)IB << (g_trsm_right_looking - 3) : 2 * IB, gflags);
 	if (g_trsm_right_looking == 1 || !work || (n < 32768 && g_trsm_right_looking != 2)) return trsm_right_looking<T>(m, n, L, ldl, winv, B, ldb, nb, st, upper_rhs, gflags);
 	if (nb <= 0) nb = trsm_auto_nb(m);

@@ -598,6 +598,29 @@ def test_trsm_many_rows_default_is_recursive(L):
 		assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 
 
+@pytest.mark.parametrize("strip", [512, 1024, 0, 1])
+def test_trsm_strip_leaf(L, strip):
+	"""fp64 recursive block solve with its 512- / 1024-column leaves as one strip launch each (stpy_tune key 17; 0 = the
+	three-launch leaves): same X as scipy for n a power of two, n with a ragged tail, and rows 16-aligned but not 128-aligned"""
+	lib = L.load()
+	lib.stpy_tune(17, strip)
+	lib.stpy_tune(5, 4)          # recursive form whatever the row count
+	try:
+		for n, m in ((2048, 2048), (1536 + 70, 144), (1024, 16)):
+			rng = np.random.RandomState(n + m + 1)
+			K = spd(rng, n)
+			Ld, winv, info = run_potrf(L, K, 0)
+			assert info == 0
+			B = rng.normal(size=(m, n))
+			Bd = dev(B)
+			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, 0, 0, None, 0, L.stream_ptr()), "trsm")
+			Xref = sla.solve_triangular(np.linalg.cholesky(K), B.T, lower=True).T
+			assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
+	finally:
+		lib.stpy_tune(17, 1)
+		lib.stpy_tune(5, 0)
+
+
 @pytest.mark.parametrize("n,d,m", [(300, 64, 512), (256, 64, 512), (384, 32, 256), (128, 96, 128), (128, 64, 192), (640, 32, 64)])
 def test_rff_f32(L, n, d, m):
 	"""fp32 embed: the dedicated 128 x 64 tile kernel (d = 32 / 64, n % 128 == 0, m % 64 == 0; m = 192 puts the cos / sin

@@ -1,5 +1,5 @@
 """stpy_trsm_right_lt over a grid of (n, m) for the values of one stpy_tune key (default 5: the block-solve algorithm), one process.
-usage: python tools/trsm_sweep.py [values, default 0,4] [key, default 5] [f64only]"""
+usage: python tools/trsm_sweep.py [values, default 0,4] [key, default 5] [f64only] [m list]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -10,6 +10,7 @@ vals = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", 
 KEY = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 KEY_DEFAULT = int(lib.stpy_tune_get(KEY))
 F64ONLY = len(sys.argv) > 3
+MLIST = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else None
 
 def factor(n, dtype):
 	code = L.dtype_code(dtype)
@@ -31,7 +32,7 @@ for dtype in ((torch.float64,) if F64ONLY else (torch.float64, torch.float32)):
 		if dtype == torch.float32 and n not in (16384, 65536):
 			continue
 		K, winv = factor(n, dtype)
-		for m in ((2048, 4096, 10112) if F64ONLY else (256, 1024, 4096, 10112)):
+		for m in (MLIST or ((2048, 4096, 10112) if F64ONLY else (256, 1024, 4096, 10112))):
 			B = torch.rand(m, n, dtype=dtype, device=dev)
 			X = torch.empty_like(B)
 			res, outs = {}, {}
