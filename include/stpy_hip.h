@@ -243,7 +243,8 @@ void stpy_profile_enable(int enable);
  *    the diagonal-block kernel on those reserved CUs (0 = never / 2048) · 14 / 15 adaptive panel width of potrf: 256 columns while
  *    at most this many rows are left, 512 up to the second value, 1024 beyond (2048 / 16384) ·
  * 16 the vector solves as one dataflow launch for n a multiple of 128 (1; 0: the chain of per-block launches) ·
- * 17 leaf width of the recursive block solve that runs as one strip launch (1 = 1024 up to 8192 rows, 512 above; 512; 1024; 0 = off) */
+ * 17 leaf width of the recursive block solve that runs as one strip launch (1 = 1024 up to 8192 rows, 512 above; 512; 1024; 0 = off) ·
+ * 18 Cholesky panels: the rows below the panel's diagonal block as one strip launch (0 = off, the default; 2 = only when nothing else runs, i.e. the first panel; 1 = always) */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */
 int stpy_tune_get(int key);

@@ -355,6 +355,8 @@ void stpy_tune(int key, int value)
 	if (key == 14) g_potrf_nb256_upto = value;
 	if (key == 15) g_potrf_nb512_upto = value;
 	if (key == 16) g_trsv_flow = value;
+	if (key == 18) g_potrf_strip = value;
+	if (key == 19) g_rff_wgs = value;
 	if (key == 17) g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0;
 }
 
@@ -380,6 +382,8 @@ int stpy_tune_get(int key)
 	case 15: return g_potrf_nb512_upto;
 	case 16: return g_trsv_flow;
 	case 17: return g_trsm_strip;
+	case 18: return g_potrf_strip;
+	case 19: return g_rff_wgs;
 	default: return -1;
 	}
 }

@@ -30,9 +30,10 @@ struct LookAhead {
 	hipStream_t side = nullptr;
 	hipEvent_t col_ready = nullptr, panel_done = nullptr, trail_done = nullptr;
 	// "reserved" mode of potrf: update stream masked off one CU per XCD, diagonal-block stream masked onto those CUs
-	hipStream_t upd = nullptr, diag = nullptr;
+	hipStream_t upd = nullptr, diag = nullptr;          // created on first use (potrf.hip: lookahead_reserved_streams)
+	bool reserved_tried = false;
 	hipEvent_t ev_diag = nullptr, ev_gemm = nullptr, ev_mode = nullptr;
-	// 16 bytes of device memory: ticket / published-count / error words of the one-launch vector solve (solve.hip)
+	// 64 bytes of device memory: ticket / published-count / error words of the one-launch vector solve (solve.hip)
 	void* trsv_sync = nullptr;
 };
 int lookahead_acquire(hipStream_t caller, LookAhead** out);
@@ -105,8 +106,13 @@ inline bool trsm_is_recursive(size_t elem, int64_t m, bool upper_rhs)
 {
 	if (g_trsm_right_looking >= 3) return true;
 	if (g_trsm_right_looking != 0 || upper_rhs) return false;
-	return m >= 2048 || (elem == 8 && g_trsm_strip > 0 && m % 16 == 0);
+	return m >= 2048 || g_trsm_strip > 0;
 }
+// X <- X L_D^-T for a diagonal block of 1..8 128-blocks in one launch (solve.hip); X2: optional second copy of the result
+template <typename T>
+int trsm_strip(int64_t m, const T* Ld, int64_t ldl, const T* W, T* X, int64_t ldx, T* X2, int64_t ldx2, int64_t w, hipStream_t st);
+bool trsm_strip_ok(size_t elem, const void* L, int64_t ldl, const void* winv);
+extern int g_potrf_strip, g_rff_wgs;
 extern int g_potrf_diag_first_below, g_potrf_beside_min, g_potrf_reserve_below, g_potrf_reserve_above;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);

@@ -121,16 +121,37 @@ __device__ __forceinline__ double gram_exp(double x)
 	return ldexp(p, (int)k);
 }
 __device__ __forceinline__ float gram_exp(float x) { return __expf(x); }
+// Table-assisted form for the fused Gram epilogue, where the 20 instructions above made the fill VALU-bound (32 fp64 instructions
+// per element = a 4.9 TB/s ceiling, profiles/r02_a_gram_rff_pmc.json):  x = (k / 256) ln2 + r with |r| <= ln2 / 512, so
+// e^x = 2^(k >> 8) * tab[k & 255] * (1 + r + r^2/2 + r^3/6 + r^4/24)  (truncation 4e-17) -- 12 fp64 instructions, two integer ones
+// and an LDS read.  tab[i] = 2^(i/256): 2 KiB of LDS filled by the workgroup with the function above.
+constexpr int GRAM_TAB = 256;
+__device__ __forceinline__ double gram_exp_tab(double x, const double* tab)
+{
+	x = fmax(x, -745.0);
+	const double k = rint(x * 369.3299304675746);       // 256 / ln2
+	double r = fma(-k, 0x1.62e42ffp-9, x);               // ln2 / 256 = hi + lo, hi with 29 significant bits: k * hi is exact
+	r = fma(-k, -1.6409824502660487e-13, r);
+	double q = fma(r, 4.1666666666666664e-02, 1.6666666666666666e-01);
+	q = fma(q, r, 0.5);
+	q = fma(q, r, 1.0);
+	q *= r;                                               // e^r - 1
+	const int ki = (int)k;
+	const double t = tab[ki & (GRAM_TAB - 1)];
+	return ldexp(fma(t, q, t), ki >> 8);
+}
+__device__ __forceinline__ float gram_exp_tab(float x, const float*) { return __expf(x); }
 
-template <typename T, int KIND> __device__ __forceinline__ T gram_value(T acc, T na, T nb)
+// hna, hnb: MINUS HALF the squared norms (so the SE exponent is two additions away from the accumulator); tab: gram_exp_tab's table
+template <typename T, int KIND> __device__ __forceinline__ T gram_value(T acc, T hna, T hnb, const T* tab)
 {
 	if (KIND == STPY_K_LINEAR) return acc;
-	const T sq = na + nb - T(2) * acc;
-	if (KIND == STPY_K_SE) return gram_exp(T(-0.5) * sq);           // no clamp, as kernels.py:395
-	const T rr = sqrt(fmax(sq, T(0)));
-	if (KIND == STPY_K_MATERN32) { const T r = rr * T(1.7320508075688772935); return (T(1) + r) * gram_exp(-r); }
+	const T x = (acc + hna) + hnb;                                   // -0.5 |a - b|^2
+	if (KIND == STPY_K_SE) return gram_exp_tab(x, tab);              // no clamp, as kernels.py:395
+	const T rr = sqrt(fmax(T(-2) * x, T(0)));
+	if (KIND == STPY_K_MATERN32) { const T r = rr * T(1.7320508075688772935); return (T(1) + r) * gram_exp_tab(-r, tab); }
 	const T r = rr * T(2.2360679774997896964);                       // MATERN52
-	return (T(1) + r + r * r * T(0.33333333333333333333)) * gram_exp(-r);
+	return (T(1) + r + r * r * T(0.33333333333333333333)) * gram_exp_tab(-r, tab);
 }
 
 // d k / d(lengthscale_m) = F * u_m^2 / lengthscale_m with u_m the scaled coordinate difference; F per family:
@@ -406,8 +427,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		// the tile's 128 + 128 norms go through LDS (the staging buffers are free after the K loop):
 		// holding them in registers next to the accumulators does not fit
 		T* const ns = smem;
-		if (tid < BN) { const int col = col0 + tid; ns[tid] = p.g_na[GUARD ? min(col, p.n - 1) : col]; }
-		else { const int row = row0 + tid - BN; ns[tid] = p.g_nb[GUARD ? min(row, p.m - 1) : row]; }
+		T* const tab = ns + 2 * BN;
+		if (tid < BN) { const int col = col0 + tid; ns[tid] = T(-0.5) * p.g_na[GUARD ? min(col, p.n - 1) : col]; }
+		else { const int row = row0 + tid - BN; ns[tid] = T(-0.5) * p.g_nb[GUARD ? min(row, p.m - 1) : row]; }
+		if constexpr (sizeof(T) == 8) tab[tid] = gram_exp(T(tid) * T(0.693147180559945309417 / GRAM_TAB));          // 256 threads, 256 entries
 		__syncthreads();
 		T na4[4];
 #pragma unroll
@@ -420,7 +443,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 				for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
-						acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)]) + p.g_offset;
+						acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)], tab) + p.g_offset;
 						// two independent exp chains at a time cover the FMA latency (two waves per SIMD fill
 						// the rest); letting the scheduler interleave all 64 costs >250 spilled VGPRs
 						if (i & 1) __builtin_amdgcn_sched_barrier(0);

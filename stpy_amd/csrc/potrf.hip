@@ -22,6 +22,10 @@ namespace stpy {
 // default outer panel width: 1024 halves the read+write passes over the trailing matrix compared
 // with 512 (measured 2 % faster end to end at N = 65 536); the solves keep 512 (see solve.hip)
 int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B runs)
+// stpy_tune key 18: the rows below a panel's diagonal block as one strip launch (solve.hip) instead of two products per 128 columns.
+// 0 (default): off; 2: only for panels factored with nothing else on the chip (the first one: no measurable difference); 1: every panel -- slower, the strip kernel's
+// 120-202 VGPRs wait for update workgroups to retire (tools/potrf_sweep.py 18=0|1: 34.8 -> 35.5 ms at N = 16 384, 1368 -> 1381 at 65 536)
+int g_potrf_strip = 0;
 // stpy_tune key 11 (0 = off, the default): blocks factored beside a trailing update take the 64-VGPR / four-wave form below.
 // Measured (tools/potrf_sweep.py, gpurun_out/potrf_sweep3.log): it is placed at once, as intended, but then RUNS 8x slower
 // beside the real update than alone (730-770 us against 94 us in the kernel trace) and loses to the eight-wave kernel that
@@ -709,6 +713,20 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 		delete la;
 		return -1002;
 	}
+	if (hipMalloc(&la->trsv_sync, 64) != hipSuccess) { (void)hipGetLastError(); la->trsv_sync = nullptr; }          // (the vector solves then take the step kernels)
+	g_la_map[key] = la;
+	*out = la;
+	return 0;
+}
+
+
+// Created on first use only (the mode is off by default, stpy_tune key 12): masked streams alive at process exit have been
+// seen to crash the profiler's finalisation.
+static void lookahead_reserved_streams(LookAhead* la)
+{
+	std::lock_guard<std::mutex> lock(g_la_mutex);
+	if (la->upd || la->reserved_tried) return;
+	la->reserved_tried = true;
 	// "reserved" mode (potrf, mid-size trailing matrices): the trailing update runs on a stream masked OFF one CU per XCD and
 	// the diagonal-block kernel on a stream masked ONTO those eight CUs.  Mask bits are dealt round-robin over the eight XCCs
 	// (tools/cumask_probe.hip: bits 0-7 = se0.cu0 of xcc0..7; an XCC whose bits are all clear gets ALL its CUs, so no XCC is
@@ -725,10 +743,6 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 			la->upd = la->diag = nullptr;
 		}
 	}
-	if (hipMalloc(&la->trsv_sync, 64) != hipSuccess) { (void)hipGetLastError(); la->trsv_sync = nullptr; }          // (the vector solves then take the step kernels)
-	g_la_map[key] = la;
-	*out = la;
-	return 0;
 }
 
 // Factor the nb-wide panel whose first column is k (its columns already carry every update from
@@ -743,12 +757,16 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 	const bool split = diag_st != nullptr && diag_st != st;
 #define FP_EV(x) do { if ((x) != hipSuccess) { set_error("potrf: event hand-over between the panel streams failed"); return -1003; } } while (0)
 	int rc;
+	// Rows below the panel's diagonal block: one strip launch after that block is factored (solve.hip: trsm_strip_kernel)
+	// instead of two products per 128 columns over all of them -- the chain of small kernels then only spans kb rows.
+	const bool strip = (g_potrf_strip == 1 || (g_potrf_strip == 2 && !(gflags & GEMM_BESIDE))) && kb % IB == 0 && kb <= 8 * IB && k + kb < n && n - k - kb < (1 << 30) && trsm_strip_ok(sizeof(T), A, lda, winv) && ldp % (int64_t)(16 / sizeof(T)) == 0;
+	const int64_t rows_end = strip ? k + kb : n;           // the per-block chain below covers rows [c, rows_end)
 	for (int64_t c = k; c < k + kb; c += IB) {
 		const int64_t cb = (n - c < IB) ? (n - c) : IB;
 		const int64_t jj = c - k;
 		if (jj > 0) {       // A[c:n, c:c+cb] -= P[c:n, 0:jj] P[c:c+cb, 0:jj]^T
-			ProfScope ps(TAG_PANEL_GEMM, 2.0 * (double)(n - c) * (double)cb * (double)jj, st);
-			rc = gemm_nt<T>(n - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
+			ProfScope ps(TAG_PANEL_GEMM, 2.0 * (double)(rows_end - c) * (double)cb * (double)jj, st);
+			rc = gemm_nt<T>(rows_end - c, cb, jj, P + c * ldp, ldp, P + c * ldp, ldp, A + c * lda + c, lda, (T*)nullptr, 0, 1, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 			if (rc) return rc;
 		}
 		hipStream_t ds = split ? diag_st : st;
@@ -760,12 +778,18 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 		if (rc) return rc;
 		if (c == k && first_diag && hipEventRecord(first_diag, ds) != hipSuccess) { set_error("potrf: event record failed"); return -1003; }
 		if (split) { FP_EV(hipEventRecord(ev_diag, ds)); FP_EV(hipStreamWaitEvent(st, ev_diag, 0)); }
-		if (c + cb < n) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
-			ProfScope ps(TAG_PANEL_GEMM, (double)(n - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
-			rc = gemm_nt<T>(n - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
+		if (c + cb < rows_end) {   // A[c+cb:n, c:c+cb] <- A[..] inverse(L_cc)^T, in place + copy into the panel
+			ProfScope ps(TAG_PANEL_GEMM, (double)(rows_end - c - cb) * (double)cb * (double)cb, st);   // triangular operand: half of 2mnk
+			rc = gemm_nt<T>(rows_end - c - cb, cb, cb, A + (c + cb) * lda + c, lda, winv + (c / IB) * IB * IB, IB,
 			                A + (c + cb) * lda + c, lda, P + (c + cb) * ldp + jj, ldp, 0, 0, st, nullptr, nullptr, nullptr, 1, nullptr, gflags);
 			if (rc) return rc;
 		}
+	}
+	if (strip) {
+		const int64_t mb = n - k - kb;
+		ProfScope ps(TAG_PANEL_GEMM, (double)mb * (double)kb * (double)kb, st);
+		rc = trsm_strip<T>(mb, A + k * lda + k, lda, winv + (k / IB) * IB * IB, A + (k + kb) * lda + k, lda, P + (k + kb) * ldp, ldp, kb, st);
+		if (rc) return rc;
 	}
 #undef FP_EV
 	return 0;
@@ -820,7 +844,9 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		// slower (in-kernel stamps, tools/potf2_stamps.py: 245-300 us against 58 us alone, every phase of it stretched alike),
 		// and it is the longest link of a chain that mid-size trailing matrices cannot hide.  With the update kept off one CU
 		// per XCD (3 % of the chip) that kernel runs alone on a reserved CU at its stand-alone speed.
-		const bool reserve = la->upd && (n - r) <= g_potrf_reserve_below && (n - r) >= g_potrf_reserve_above && !(gflags & GEMM_BESIDE);
+		const bool want_reserve = (n - r) <= g_potrf_reserve_below && (n - r) >= g_potrf_reserve_above && !(gflags & GEMM_BESIDE);
+		if (want_reserve && !la->upd) lookahead_reserved_streams(la);
+		const bool reserve = want_reserve && la->upd && (n - r) <= g_potrf_reserve_below && (n - r) >= g_potrf_reserve_above && !(gflags & GEMM_BESIDE);
 		rc = switch_to(reserve ? la->upd : st);
 		if (rc) return rc;
 		{   // next panel's block column (all rows below r)

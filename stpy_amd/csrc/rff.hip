@@ -17,6 +17,7 @@
 
 namespace stpy {
 
+int g_rff_wgs = 0;              // stpy_tune key 19: workgroups of the streaming kernel (0 = 512, two per CU)
 int g_rff_tile = 1;             // dedicated fp32 kernels (stpy_tune key 9): 1 = streaming kernel for large d = 64 shapes, tile kernel for
                                 // the other d = 32 / 64 shapes; 2 = tile kernel only; 0 = always the GEMM epilogue
 
@@ -392,7 +393,7 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 	if (!feat_scale && g_rff_tile >= 1 && g_rff_tile != 2 && !transposed && d == 64 && n % 128 == 0 && m % 1024 == 0 && n >= 8192 && ldw < ((int64_t)1 << 27) && ldo < ((int64_t)1 << 28) && ldx % 4 == 0 && ldw % 4 == 0 &&
 	    ldo % 4 == 0 && (((uintptr_t)x | (uintptr_t)W | (uintptr_t)out) & 15) == 0 && n / 128 < (int64_t)INT32_MAX && m < (int64_t)INT32_MAX) {
 		const int row_blocks = (int)(n / 128);
-		int wgs = 512;                                                   // two per CU; a multiple of eight (one column part per XCD)
+		int wgs = g_rff_wgs > 0 ? (g_rff_wgs + 7) / 8 * 8 : 512;          // two per CU; a multiple of eight (one column part per XCD); stpy_tune key 19
 		if (wgs > 8 * row_blocks) wgs = 8 * row_blocks;
 		if (g_rff_tile == 3) hipLaunchKernelGGL(rff_stream_direct_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
 		else hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);

@@ -40,64 +40,75 @@ static int solve_panel(int64_t m, int64_t n, int64_t k, int64_t kb, const T* L, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Leaf of the recursive block solve as ONE launch: X[:, c0 : c0 + 128 NBLK] <- X L_D^-T for the NBLK x NBLK diagonal block
-// D of L (fp64, rows a multiple of 16).  Through the recursion such a leaf is 3 launches per 256 columns plus the small
-// products of the levels above it -- 32-128 tiles each on a chip with 512 workgroup slots: at n = 16 384, M = 4096 the levels
-// below 1024 columns take ~5 of 24 ms for 2 % of the flops.  Here a workgroup owns 16 rows for the whole leaf:
+// X <- X L_D^-T for an NBLK x NBLK block D of 128-blocks on the diagonal of L, as ONE launch ("strip" kernel).
+// Used as the leaf of the recursive block solve and for the rows below the diagonal block of a Cholesky panel.
+// Through the recursion a leaf is 3 launches per 256 columns plus the small products of the levels above it -- 32-128 tiles
+// each on a chip with 512 workgroup slots: at n = 16 384, M = 4096 the levels below 1024 columns took ~5 of 24 ms for 2 % of
+// the flops.  Here a workgroup owns 16 rows for the whole block:
 //   * its 16 x (128 NBLK) strip lives in the MFMA accumulators (wave w: the 32-column quarter w of every 128-block);
 //   * block j: the strip's block (already carrying - sum_{i<j} X_i L_ji^T) goes through LDS to become the A operand of
 //     X_j = . W_j^T (W_j = inverse(L_jj), cached), X_j is stored, goes through LDS again and updates the later blocks
 //     acc_jj -= X_j L_jj,j^T;
 //   * the B operands (W_j, L_jj,j: 128 x 128, shared by every workgroup, L2-resident) are read straight into registers one
 //     K tile ahead -- no LDS staging, no barrier inside a product.
+// Rows beyond m are read as zero and not stored.  X2 (optional): a second copy of the result (the Cholesky panel workspace).
 // ------------------------------------------------------------------------------------------
-constexpr int TS_ROWS = 16, TS_LD = IB + 2;          // LDS row stride 130 doubles: 16 lanes reading 16 rows hit 16 different 4-bank groups
-template <int NBLK>
+constexpr int TS_ROWS = 16;
+template <typename T, int NBLK>
 __global__ __launch_bounds__(256)
-void trsm_strip_kernel(const double* __restrict__ L, int64_t ldl, const double* __restrict__ W, double* __restrict__ X, int64_t ldx, int c0)
+void trsm_strip_kernel(const T* __restrict__ Ld, int64_t ldl, const T* __restrict__ W, T* __restrict__ X, int64_t ldx, T* __restrict__ X2, int64_t ldx2, int m)
 {
-	typedef Mfma<double> MM;
-	typedef MM::v4 v4;
-	typedef double d2 __attribute__((ext_vector_type(2)));
-	__shared__ __attribute__((aligned(16))) double tile[TS_ROWS * TS_LD];
+	typedef Mfma<T> MM;
+	typedef typename MM::v4 v4;
+	constexpr int CE = 16 / (int)sizeof(T);                  // elements of a 16-byte chunk: 2 doubles / 4 floats
+	constexpr int NCH = 4 / CE;                              // chunks per lane and K tile of 16: each lane supplies 4 of the 16 k's
+	constexpr int TS_LD = IB + 16 / (int)sizeof(T) * 1;      // LDS row stride 130 doubles / 132 floats: 16 rows -> 16 different 4-bank groups
+	typedef T chunk __attribute__((ext_vector_type(CE)));
+	__shared__ __attribute__((aligned(16))) T tile[TS_ROWS * TS_LD];
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, g = lane >> 4;
 	const int64_t row0 = (int64_t)blockIdx.x * TS_ROWS;
-	double* const xs = X + row0 * ldx + c0;          // this workgroup's strip
+	T* const xs = X + row0 * ldx;          // this workgroup's strip (the pointers are already at the block's first column)
+	T* const xs2 = X2 ? X2 + row0 * ldx2 : nullptr;
+	const int rows_left = m - (int)row0;   // rows of this strip that exist
 
-	// accumulators: acc[j][t] = rows (lane>>4) + 4 i, column 128 j + 32 wave + 16 t + r16
+	// accumulators: acc[j][t][i] = row crow(lane, i), column 128 j + 32 wave + 16 t + r16
 	v4 acc[NBLK][2];
 #pragma unroll
 	for (int j = 0; j < NBLK; ++j)
 #pragma unroll
 		for (int t = 0; t < 2; ++t)
 #pragma unroll
-			for (int i = 0; i < 4; ++i) acc[j][t][i] = xs[(int64_t)(g + 4 * i) * ldx + 128 * j + 32 * wave + 16 * t + r16];
+			for (int i = 0; i < 4; ++i) {
+				const int r = MM::crow(lane, i);
+				acc[j][t][i] = r < rows_left ? xs[(int64_t)r * ldx + 128 * j + 32 * wave + 16 * t + r16] : T(0);
+			}
 
-	// C fragment -> LDS tile (16 x 128, K-contiguous rows): the A operand of the next product
-	auto to_tile = [&](const v4 (&c)[2]) {
+	// C fragment -> LDS tile (16 x 128, K-contiguous rows): the A operand of the next product.  NEG: the tile holds -c (fp32 has
+	// no negating MFMA; the subtracting products then accumulate (-X_j) L^T)
+	auto to_tile = [&](const v4 (&c)[2], bool neg) {
 #pragma unroll
 		for (int t = 0; t < 2; ++t)
 #pragma unroll
-			for (int i = 0; i < 4; ++i) tile[(g + 4 * i) * TS_LD + 32 * wave + 16 * t + r16] = c[t][i];
+			for (int i = 0; i < 4; ++i) tile[MM::crow(lane, i) * TS_LD + 32 * wave + 16 * t + r16] = neg ? -c[t][i] : c[t][i];
 	};
 	// out[t] (+|-)= tile (16 x 128) * Bblk[32 wave + 16 t + r16][0:128]^T ; Bblk row-major with leading dimension ldb
-	auto product = [&](auto sub_tag, v4 (&out)[2], const double* Bblk, int64_t ldb) {
-		constexpr bool SUBT = decltype(sub_tag)::value;
-		const double* brow0 = Bblk + (int64_t)(32 * wave + r16) * ldb + 2 * g * 2;          // chunk 2g of row (tile 0)
-		const double* brow1 = brow0 + 16 * ldb;
-		const double* arow = tile + r16 * TS_LD + 2 * g * 2;
-		d2 b0[2][2], b1[2][2];          // [tile][half] for K tile kt (b0) and kt + 1 (b1)
-		auto loadb = [&](d2 (&b)[2][2], int kt) {
+	auto product = [&](auto sub_tag, v4 (&out)[2], const T* Bblk, int64_t ldb) {
+		constexpr bool SUBT = decltype(sub_tag)::value && MM::HAS_NEG;
+		const T* brow0 = Bblk + (int64_t)(32 * wave + r16) * ldb + NCH * g * CE;          // lane group g: chunks NCH g .. of every K tile
+		const T* brow1 = brow0 + 16 * ldb;
+		const T* arow = tile + r16 * TS_LD + NCH * g * CE;
+		chunk b0[2][NCH], b1[2][NCH];          // [tile][chunk] for K tile kt (b0) and kt + 1 (b1)
+		auto loadb = [&](chunk (&b)[2][NCH], int kt) {
 #pragma unroll
-			for (int h = 0; h < 2; ++h) { b[0][h] = *(const d2*)(brow0 + kt * 16 + 2 * h); b[1][h] = *(const d2*)(brow1 + kt * 16 + 2 * h); }
+			for (int h = 0; h < NCH; ++h) { b[0][h] = *(const chunk*)(brow0 + kt * 16 + CE * h); b[1][h] = *(const chunk*)(brow1 + kt * 16 + CE * h); }
 		};
-		auto step = [&](const d2 (&b)[2][2], int kt) {
+		auto step = [&](const chunk (&b)[2][NCH], int kt) {
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				const d2 a = *(const d2*)(arow + kt * 16 + 2 * h);
+			for (int h = 0; h < NCH; ++h) {
+				const chunk a = *(const chunk*)(arow + kt * 16 + CE * h);
 #pragma unroll
-				for (int s2 = 0; s2 < 2; ++s2)
+				for (int s2 = 0; s2 < CE; ++s2)
 #pragma unroll
 					for (int t = 0; t < 2; ++t) out[t] = SUBT ? MM::mms(a[s2], b[t][h][s2], out[t]) : MM::mma(a[s2], b[t][h][s2], out[t]);
 			}
@@ -114,21 +125,27 @@ void trsm_strip_kernel(const double* __restrict__ L, int64_t ldl, const double* 
 
 #pragma unroll
 	for (int j = 0; j < NBLK; ++j) {
-		to_tile(acc[j]);
+		to_tile(acc[j], false);
 		__syncthreads();
 		v4 xj[2] = {v4{0, 0, 0, 0}, v4{0, 0, 0, 0}};
-		product(std::false_type{}, xj, W + (int64_t)(c0 / IB + j) * IB * IB, IB);          // X_j = (.) inverse(L_jj)^T
+		product(std::false_type{}, xj, W + (int64_t)j * IB * IB, IB);          // X_j = (.) inverse(L_jj)^T
 #pragma unroll
 		for (int t = 0; t < 2; ++t)
 #pragma unroll
-			for (int i = 0; i < 4; ++i) xs[(int64_t)(g + 4 * i) * ldx + 128 * j + 32 * wave + 16 * t + r16] = xj[t][i];
+			for (int i = 0; i < 4; ++i) {
+				const int r = MM::crow(lane, i);
+				if (r < rows_left) {
+					xs[(int64_t)r * ldx + 128 * j + 32 * wave + 16 * t + r16] = xj[t][i];
+					if (xs2) xs2[(int64_t)r * ldx2 + 128 * j + 32 * wave + 16 * t + r16] = xj[t][i];
+				}
+			}
 		if (j + 1 < NBLK) {
 			__syncthreads();                     // everybody has read the tile
-			to_tile(xj);
+			to_tile(xj, !MM::HAS_NEG);
 			__syncthreads();
 #pragma unroll
 			for (int jj = j + 1; jj < NBLK; ++jj)
-				product(std::true_type{}, acc[jj], L + (int64_t)(c0 + 128 * jj) * ldl + c0 + 128 * j, ldl);          // acc_jj -= X_j L_jj,j^T
+				product(std::true_type{}, acc[jj], Ld + (int64_t)(128 * jj) * ldl + 128 * j, ldl);          // acc_jj -= X_j L_jj,j^T
 			__syncthreads();
 		}
 	}
@@ -137,20 +154,26 @@ void trsm_strip_kernel(const double* __restrict__ L, int64_t ldl, const double* 
 int g_trsm_strip = 1;            // stpy_tune key 17: leaf width of the recursive block solve handled by trsm_strip_kernel (0 = off; 512; 1024;
                                  // 1 = by row count: 1024 while the m / 16 workgroups fit the chip at once (202 VGPRs: two per CU), 512 above)
 
+// Ld: the diagonal block's first element (L + c0 * ldl + c0); W: its first inverse 128-block; X / X2 at the block's first column.
 template <typename T>
-static int trsm_strip(int64_t m, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int64_t c0, int64_t w, hipStream_t st)
+int trsm_strip(int64_t m, const T* Ld, int64_t ldl, const T* W, T* X, int64_t ldx, T* X2, int64_t ldx2, int64_t w, hipStream_t st)
 {
-	if constexpr (sizeof(T) == 8) {
-		const dim3 grid((unsigned)(m / TS_ROWS)), block(256);
-		switch ((int)(w / IB)) {
-#define STPY_STRIP(NB) case NB: hipLaunchKernelGGL((trsm_strip_kernel<NB>), grid, block, 0, st, L, ldl, winv, B, ldb, (int)c0); break;
-			STPY_STRIP(1) STPY_STRIP(2) STPY_STRIP(3) STPY_STRIP(4) STPY_STRIP(5) STPY_STRIP(6) STPY_STRIP(7) STPY_STRIP(8)
+	if (m <= 0) return 0;
+	if (w % IB != 0 || w > 8 * IB || m > (int64_t)TS_ROWS * 0x7fffff00 / 256 * 256 || ldl % (16 / sizeof(T)) != 0 ||
+	    (((uintptr_t)Ld | (uintptr_t)W) & 15) != 0) { set_error("trsm strip: unsupported shape / alignment"); return -2; }
+	const dim3 grid((unsigned)((m + TS_ROWS - 1) / TS_ROWS)), block(256);
+	switch ((int)(w / IB)) {
+#define STPY_STRIP(NB) case NB: hipLaunchKernelGGL((trsm_strip_kernel<T, NB>), grid, block, 0, st, Ld, ldl, W, X, ldx, X2, ldx2, (int)m); break;
+		STPY_STRIP(1) STPY_STRIP(2) STPY_STRIP(3) STPY_STRIP(4) STPY_STRIP(5) STPY_STRIP(6) STPY_STRIP(7) STPY_STRIP(8)
 #undef STPY_STRIP
-			default: set_error("trsm strip leaf: width %lld", (long long)w); return -2;
-		}
-		return check_launch("trsm (strip leaf)");
 	}
-	return -1;
+	return check_launch("trsm (strip)");
+}
+template int trsm_strip<double>(int64_t, const double*, int64_t, const double*, double*, int64_t, double*, int64_t, int64_t, hipStream_t);
+template int trsm_strip<float>(int64_t, const float*, int64_t, const float*, float*, int64_t, float*, int64_t, int64_t, hipStream_t);
+bool trsm_strip_ok(size_t elem, const void* L, int64_t ldl, const void* winv)
+{
+	return ldl % (int64_t)(16 / elem) == 0 && (((uintptr_t)L | (uintptr_t)winv) & 15) == 0;
 }
 
 #define HIPCHK_S(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("trsm: %s failed: %s", #x, hipGetErrorString(e_)); return -1000 - (int)e_; } } while (0)
@@ -202,10 +225,11 @@ template <typename T>
 static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int64_t leaf, int gflags)
 {
 	const int64_t strip_w = g_trsm_strip == 1 ? (m <= 8192 ? 1024 : 512) : g_trsm_strip;
-	if (sizeof(T) == 8 && strip_w > 0 && w <= strip_w && w % IB == 0 && !upper_rhs && m % TS_ROWS == 0 && c0 + w <= n && ldl % 2 == 0 && ldb % 2 == 0 &&
-	    m / TS_ROWS < 65536 * (int64_t)32768 && (((uintptr_t)L | (uintptr_t)B | (uintptr_t)winv) & 15) == 0 && c0 < (1 << 30)) {
+	// (not beside a trailing update: the strip kernel's 120-202 VGPRs do not fit next to two update workgroups; there the
+	// 64-VGPR sliver products of solve_panel stay ahead -- potrf panels with the strip: 35.5 against 34.8 ms at N = 16 384)
+	if (strip_w > 0 && !(gflags & GEMM_BESIDE) && w <= strip_w && w % IB == 0 && !upper_rhs && c0 + w <= n && m < (1 << 30) && trsm_strip_ok(sizeof(T), L, ldl, winv)) {
 		ProfScope ps(TAG_TRSM_GEMM, (double)m * (double)w * (double)w, st);
-		return trsm_strip<T>(m, L, ldl, winv, B, ldb, c0, w, st);
+		return trsm_strip<T>(m, L + c0 * ldl + c0, ldl, winv + (c0 / IB) * IB * IB, B + c0, ldb, (T*)nullptr, 0, w, st);
 	}
 	if (w <= leaf) return solve_panel<T>(m, n, c0, w, L, ldl, winv, B, ldb, st, upper_rhs, gflags);
 	int64_t h = IB;
