@@ -217,10 +217,15 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
  *   (cosine-only grids pass a zero bias).
  * transposed != 0 writes Phi^T instead (out: m x n, out[j*ldo + i]) -- the "row x K" operand the
  * feature-space normal equations Phi^T Phi need (kernelized_features.py:236-240).
+ * work (optional, stpy_rff_workspace_bytes; 0 for most shapes): with it the large fp32 d = 64 shapes take the contraction to
+ *   the bf16 matrix cores from an EXACT three-way bf16 split of both fp32 operands (six products, fp32 accumulation: the
+ *   dropped terms are below one fp32 rounding) -- the fp32 MFMA shares the SIMD's ALUs with the trig work, the bf16 pipe does
+ *   not.  The workspace receives the split W (m * 64 * 6 bytes); NULL keeps the fp32-MFMA kernel.  Undersized: -20.
  */
+int64_t stpy_rff_workspace_bytes(int dtype, int64_t n, int d, int64_t m);
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
                    const void* W, int64_t ldw, int64_t m, const void* bias, const void* feat_scale, double scale,
-                   void* out, int64_t ldo, int transposed, void* stream);
+                   void* out, int64_t ldo, int transposed, void* work, int64_t work_bytes, void* stream);
 
 /*
  * Launch profiler (bench.py's live roofline numbers).  While enabled, HIP events are recorded on

@@ -47,7 +47,8 @@ SIGNATURES = {
 	"stpy_gemm_nt_splitk": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
 	"stpy_gemm_nt_bc": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 	"stpy_symmetrize_lower": (_i32, [_i32, _i64, _vp, _i64, _vp]),
-	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _dbl, _vp, _i64, _i32, _vp]),
+	"stpy_rff_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
+	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _dbl, _vp, _i64, _i32, _vp, _i64, _vp]),
 	"stpy_profile_enable": (None, [_i32]),
 	"stpy_profile_read_union": (_i32, [_i32, _c.POINTER(_dbl), _c.POINTER(_dbl), _c.POINTER(_i64)]),
 	"stpy_tune": (None, [_i32, _i32]),

@@ -323,16 +323,24 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
 	DISPATCH(dtype, symmetrize_lower<double>(n, (double*)A, lda, st), symmetrize_lower<float>(n, (float*)A, lda, st));
 }
 
+int64_t stpy_rff_workspace_bytes(int dtype, int64_t n, int d, int64_t m)
+{
+	if (n <= 0 || m <= 0 || d <= 0) return 0;
+	return rff_workspace_bytes(dtype == STPY_F32 ? 4 : 8, n, d, m);
+}
+
 int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, const void* W, int64_t ldw, int64_t m,
-                   const void* bias, const void* feat_scale, double scale, void* out, int64_t ldo, int transposed, void* stream)
+                   const void* bias, const void* feat_scale, double scale, void* out, int64_t ldo, int transposed,
+                   void* work, int64_t work_bytes, void* stream)
 {
 	if (n <= 0 || m <= 0) return 0;
 	if (!x || !W || !out) { set_error("stpy_rff_embed: null pointer"); return -2; }
 	if (d <= 0 || ldx < d || ldw < d || ldo < (transposed ? n : m)) { set_error("stpy_rff_embed: bad dimensions"); return -5; }
+	if (work) WORK_CHECK("stpy_rff_embed", work_bytes, stpy_rff_workspace_bytes(dtype, n, d, m));
 	hipStream_t st = (hipStream_t)stream;
 	DISPATCH(dtype,
-	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, (const double*)feat_scale, scale, (double*)out, ldo, transposed, st),
-	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, (const float*)feat_scale, scale, (float*)out, ldo, transposed, st));
+	         rff_embed<double>((const double*)x, n, ldx, d, (const double*)W, ldw, m, (const double*)bias, (const double*)feat_scale, scale, (double*)out, ldo, transposed, work, work_bytes, st),
+	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, (const float*)feat_scale, scale, (float*)out, ldo, transposed, work, work_bytes, st));
 }
 
 /* experiment knobs (benchmarks only): key 0 = gemm first-round stagger on/off */

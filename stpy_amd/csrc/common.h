@@ -141,6 +141,7 @@ int gram_diag(int kind, const T* x, int64_t m, int64_t ldx, int d, const int32_t
               double kappa, double offset, int combine, T* out, hipStream_t st);
 template <typename T>
 int rff_embed(const T* x, int64_t n, int64_t ldx, int d, const T* W, int64_t ldw, int64_t m,
-              const T* bias, const T* feat_scale, double scale, T* out, int64_t ldo, int transposed, hipStream_t st);
+              const T* bias, const T* feat_scale, double scale, T* out, int64_t ldo, int transposed, void* work, int64_t work_bytes, hipStream_t st);
+int64_t rff_workspace_bytes(int elem, int64_t n, int d, int64_t m);
 
 }  // namespace stpy

@@ -85,8 +85,12 @@ class RFFEmbedding(Embedding):
 		shape = (self.m, times) if transposed else (times, self.m)
 		out = torch.empty(shape, dtype=xd.dtype, device=xd.device)
 		scale = float(np.sqrt(2. / float(self.m)) * np.sqrt(self.kappa))
+		# (large fp32 d = 64 shapes: a workspace for the split W lets the contraction run on the bf16 matrix cores; 0 bytes otherwise)
+		wb = 0 if transposed else int(lib.stpy_rff_workspace_bytes(_lib.dtype_code(xd.dtype), times, d, self.m))
+		work = torch.empty((wb,), dtype=torch.uint8, device=xd.device) if wb > 0 else None
 		rc = lib.stpy_rff_embed(_lib.dtype_code(xd.dtype), _lib.ptr(xd), times, xd.stride(0), d, _lib.ptr(Wd), Wd.stride(0),
-								self.m, _lib.ptr(bd), None, scale, _lib.ptr(out), out.stride(0), 1 if transposed else 0, _lib.stream_ptr())
+								self.m, _lib.ptr(bd), None, scale, _lib.ptr(out), out.stride(0), 1 if transposed else 0,
+								_lib.ptr(work), wb, _lib.stream_ptr())
 		_lib.check(rc, "stpy_rff_embed")
 		return out
 
@@ -180,8 +184,7 @@ class QuadratureEmbedding(Embedding):
 		m = Wd.shape[0]
 		out = torch.empty((m, times) if transposed else (times, m), dtype=xd.dtype, device=xd.device)
 		rc = lib.stpy_rff_embed(_lib.dtype_code(xd.dtype), _lib.ptr(xd), times, xd.stride(0), d, _lib.ptr(Wd), Wd.stride(0), m,
-								_lib.ptr(bias), _lib.ptr(amp), float(np.sqrt(self.kappa)), _lib.ptr(out), out.stride(0), 1 if transposed else 0,
-								_lib.stream_ptr())
+								_lib.ptr(bias), _lib.ptr(amp), float(np.sqrt(self.kappa)), _lib.ptr(out), out.stride(0), 1 if transposed else 0, None, 0, _lib.stream_ptr())
 		_lib.check(rc, "stpy_rff_embed")
 		return out
 

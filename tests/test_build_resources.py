@@ -105,6 +105,26 @@ def test_rff_tile_kernel_fits_three_per_cu(tmp_path):
 	assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", stream[0]).group(1)) == 0
 	assert int(re.search(r"\bVGPRs: (\d+)", stream[0]).group(1)) <= 256
 	assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", stream[0]).group(1)) >= 2
+	# the bf16-matrix-core form (production instantiation <0>): two waves per SIMD, both staging patches of two workgroups inside
+	# one CU's LDS; it sits AT the 256-VGPR limit -- the row-block prologue and the first two tiles may spill, the steady-state
+	# tile loop may not (checked on the assembly below)
+	split = [b for b in allb if "rff_stream_bf16x3_kernelILi0" in b.split()[0]]
+	assert len(split) == 1
+	assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", split[0]).group(1)) >= 2
+	assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", split[0]).group(1)) <= 80 * 1024
+	assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", split[0]).group(1)) <= 200
+	asm = tmp_path / "rff.s"
+	subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-S", "--cuda-device-only",
+					os.path.join(CSRC, "rff.hip"), "-o", str(asm)], capture_output=True, text=True, check=True)
+	src = asm.read_text()
+	body = src[src.index("_ZN4stpy24rff_stream_bf16x3_kernelILi0"):]
+	body = body[body.index(":\n"):body.index(".amdhsa_kernel")]
+	steady = 0
+	for blk in re.split(r"\n\.LBB\d+_\d+:", body):
+		if blk.count("v_mfma_f32_16x16x32_bf16") == 96 and blk.count("global_store_dwordx4") == 8:          # a steady-state tile: all MFMAs + the spread stores
+			steady += 1
+			assert "scratch_" not in blk
+	assert steady == 2
 	blocks = [b for b in allb if "rff_tile_f32_kernel" in b.split()[0]]
 	assert len(blocks) == 2
 	for b in blocks:

@@ -559,9 +559,9 @@ def test_rff(L, n, d, m):
 	out = torch.empty((n, m), dtype=torch.float64, device="cuda:0")
 	scale = np.sqrt(2.0 / m) * np.sqrt(2.5)
 	xd, Wd, bd = dev(x), dev(W), dev(b)          # keep the device buffers alive across the launches
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, None, 0, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5)) < 1e-14
-	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F64, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), m, 0, None, 0, L.stream_ptr()), "rff")
 	assert rel_err(out.cpu().numpy(), O.rff_embed(x, W, m, kappa=2.5, b=b).T) < 1e-14
 
 
@@ -574,10 +574,10 @@ def test_rff_transposed(L, dtype, tol):
 	xd, Wd, bd = dev(x, dtype), dev(W, dtype), dev(b, dtype)
 	out = torch.empty((m, n), dtype=dtype, device="cuda:0")
 	scale = np.sqrt(2.0 / m)
-	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), n, 1, None, 0, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x, W, m).T
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
-	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.dtype_code(dtype), L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), n, 1, None, 0, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x, W, m, b=b)          # the reference's biased orientation is already (m, n)
 	assert np.abs(out.cpu().numpy() - ref).max() < tol * 10 * np.abs(ref).max() + tol * 1e-2
 
@@ -634,16 +634,16 @@ def test_rff_f32(L, n, d, m):
 	x64, W64, b64 = x.astype(np.float64), W.astype(np.float64), b.astype(np.float64)
 	scale = float(np.sqrt(2.0 / m))
 	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, None, 0, L.stream_ptr()), "rff")
 	ref = O.rff_embed(x64, W64, m)
 	assert np.abs(out.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(out), m, 0, None, 0, L.stream_ptr()), "rff")
 	refb = O.rff_embed(x64, W64, m, b=b64)            # (m, n) in the reference's biased orientation
 	assert np.abs(out.cpu().numpy() - refb.T).max() < 2e-5 * np.abs(refb).max()
 	outT = torch.empty((m, n), dtype=torch.float32, device="cuda:0")
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(outT), n, 1, None, 0, L.stream_ptr()), "rff")
 	assert np.abs(outT.cpu().numpy() - ref.T).max() < 2e-5 * np.abs(ref).max()
-	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(outT), n, 1, L.stream_ptr()), "rff")
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bd), None, scale, L.ptr(outT), n, 1, None, 0, L.stream_ptr()), "rff")
 	assert np.abs(outT.cpu().numpy() - refb).max() < 2e-5 * np.abs(refb).max()
 
 
@@ -663,7 +663,7 @@ def test_rff_f32_tile_kernel_matches_gemm_epilogue(L):
 			lib.stpy_tune(9, route)
 			for bias in (None, bd):
 				out = torch.full((n, ldo), 7.0, dtype=torch.float32, device="cuda:0")
-				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), ldo, 0, L.stream_ptr()), "rff")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), ldo, 0, None, 0, L.stream_ptr()), "rff")
 				outs[(route, bias is not None)] = out.cpu().numpy()
 	finally:
 		lib.stpy_tune(9, 1)
@@ -673,6 +673,58 @@ def test_rff_f32_tile_kernel_matches_gemm_epilogue(L):
 		assert np.abs(a[:, :m] - g[:, :m]).max() < 1e-5 * np.abs(g[:, :m]).max()
 	ref = O.rff_embed(x.astype(np.float64), W.astype(np.float64), m)
 	assert np.abs(outs[(1, False)][:, :m] - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_rff_f32_bf16_split_kernel(L):
+	"""Large fp32 d = 64 shapes WITH the workspace: the contraction runs on the bf16 matrix cores from an exact three-way split
+	of both operands.  Same result as the fp32-MFMA kernel to fp32 rounding level and as the oracle within the fp32 tolerance --
+	on well-scaled inputs and on inputs that stress the split: mixed signs, 1e-6 .. 1e3 dynamic range inside a row, exact zeros,
+	phases of tens of revolutions; plain and biased; a row count that leaves the last stride of row blocks partly idle."""
+	lib = L.load()
+	n, d, m = 8192 + 3 * 128, 64, 2048
+	wb = int(lib.stpy_rff_workspace_bytes(L.F32, n, d, m))
+	assert wb == m * 64 * 6
+	assert int(lib.stpy_rff_workspace_bytes(L.F32, n, 32, m)) == 0 and int(lib.stpy_rff_workspace_bytes(L.F64, n, d, m)) == 0
+	assert int(lib.stpy_rff_workspace_bytes(L.F32, 4096, d, m)) == 0 and int(lib.stpy_rff_workspace_bytes(L.F32, n, d, m + 64)) == 0
+	work = torch.empty(wb, dtype=torch.uint8, device="cuda:0")
+	rng = np.random.RandomState(7)
+	scale = float(np.sqrt(2.0 / m))
+	cases = {}
+	cases["well scaled"] = (rng.uniform(-2, 2, size=(n, d)), rng.normal(size=(m, d)) / 4.0)
+	xs = rng.uniform(-1, 1, size=(n, d)) * 10.0 ** rng.uniform(-6, 1, size=(n, d))
+	xs[rng.uniform(size=(n, d)) < 0.1] = 0.0
+	ws = rng.normal(size=(m, d)) * 10.0 ** rng.uniform(-3, 0.5, size=(m, d))
+	cases["wide range, zeros"] = (xs, ws)
+	cases["many revolutions"] = (rng.uniform(-8, 8, size=(n, d)), rng.normal(size=(m, d)) * 2.0)
+	b = (2 * np.pi * rng.uniform(size=m)).astype(np.float32)
+	bd = dev(b, torch.float32)
+	for name, (x, W) in cases.items():
+		x, W = x.astype(np.float32), W.astype(np.float32)
+		xd, Wd = dev(x, torch.float32), dev(W, torch.float32)
+		phase = np.abs(x[:256].astype(np.float64) @ W.astype(np.float64).T).max()
+		# fp32 arithmetic resolves a phase of p radians to about p * 2^-23 (inputs) + the accumulation of 64 products
+		tol = max(2e-5, 6e-6 * phase)
+		for bias, bnp in ((None, None), (bd, b)):
+			got = {}
+			for use_ws in (True, False):
+				out = torch.full((n, m), 7.0, dtype=torch.float32, device="cuda:0")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), m, 0,
+										   L.ptr(work) if use_ws else None, wb if use_ws else 0, L.stream_ptr()), "rff")
+				got[use_ws] = out.cpu().numpy()
+			assert np.abs(got[True]).max() <= scale * (1 + 1e-6), name          # every element written (the fill value was 7)
+			rows = np.r_[0:128, n - 128:n]
+			ref = O.rff_embed(x[rows].astype(np.float64), W.astype(np.float64), m, b=None if bnp is None else bnp.astype(np.float64))
+			ref = ref.T if bnp is not None else ref
+			e_split = np.abs(got[True][rows] - ref).max() / scale
+			e_f32 = np.abs(got[False][rows] - ref).max() / scale
+			assert e_split < tol, (name, e_split, tol)
+			assert e_split < 3 * e_f32 + 2e-6, (name, e_split, e_f32)          # as accurate as the fp32-MFMA kernel
+			assert np.abs(got[True] - got[False]).max() / scale < 2 * tol, name
+	# an undersized workspace is refused, not overrun
+	out = torch.empty((n, m), dtype=torch.float32, device="cuda:0")
+	xd, Wd = dev(cases["well scaled"][0].astype(np.float32), torch.float32), dev(cases["well scaled"][1].astype(np.float32), torch.float32)
+	rc = lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, L.ptr(work), wb - 16, L.stream_ptr())
+	assert rc == -20 and b"workspace" in lib.stpy_last_error_string()
 
 
 def test_rff_f32_streaming_kernel(L):
@@ -691,7 +743,7 @@ def test_rff_f32_streaming_kernel(L):
 			lib.stpy_tune(9, route)
 			for bias in (None, bd):
 				out = torch.full((n, m), 7.0, dtype=torch.float32, device="cuda:0")
-				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), m, 0, L.stream_ptr()), "rff")
+				L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, L.ptr(bias) if bias is not None else None, None, scale, L.ptr(out), m, 0, None, 0, L.stream_ptr()), "rff")
 				outs[(route, bias is not None)] = out.cpu().numpy()
 	finally:
 		lib.stpy_tune(9, 1)

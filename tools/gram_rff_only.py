@@ -32,6 +32,6 @@ if "rff" in which:
 	W = (torch.randn(m, d, generator=g, dtype=torch.float32) / 8.0).to(dev)
 	z = torch.empty((n, m), dtype=torch.float32, device=dev)
 	for _ in range(3):
-		L.check(lib.stpy_rff_embed(L.F32, L.ptr(xr), n, d, d, L.ptr(W), d, m, None, None, math.sqrt(2.0 / m), L.ptr(z), m, 0, L.stream_ptr()), "rff")
+		L.check(lib.stpy_rff_embed(L.F32, L.ptr(xr), n, d, d, L.ptr(W), d, m, None, None, math.sqrt(2.0 / m), L.ptr(z), m, 0, None, 0, L.stream_ptr()), "rff")
 	torch.cuda.synchronize()
 print("done")
