@@ -277,10 +277,12 @@ def main():
 		os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
 	if dist_path:
 		import torch.distributed as dist
+		import datetime
+		# a collective that never completes must end the run with an error line, not sit in the driver's clock: 4-minute watchdog
 		if backend == "nccl":
-			dist.init_process_group(backend="nccl", device_id=dev)
+			dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=4))
 		else:
-			dist.init_process_group(backend=backend)
+			dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=4))
 
 	from stpy_amd import GaussianProcess, _lib
 	lib = _lib.load()

@@ -21,7 +21,7 @@ import sys
 PEAK_FP64 = 78.6e12
 
 FAMILIES = [
-	("gemm", re.compile(r"stpy::gemm_nt_(dtv_|k128_|sliver_)?kernel")),
+	("gemm", re.compile(r"stpy::(gemm_nt_(dtv_|k128_|sliver_)?kernel|trsm_strip_kernel)")),
 	("diag_block", re.compile(r"stpy::potf2_trtri")),
 	("panel_fused", re.compile(r"stpy::panel_")),
 	("trsv", re.compile(r"stpy::trsv_")),
