@@ -444,9 +444,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
 						acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)], tab) + p.g_offset;
-						// two independent exp chains at a time cover the FMA latency (two waves per SIMD fill
-						// the rest); letting the scheduler interleave all 64 costs >250 spilled VGPRs
-						if (i & 1) __builtin_amdgcn_sched_barrier(0);
+						// four independent exp chains at a time cover the FMA latency and the LDS round trip of the table
+						// read (two measure the same: the epilogue is bound by instruction issue -- 17 VALU per element at
+						// ~7.5 cycles in this kernel -- not by latency); letting the scheduler interleave all 64 costs
+						// >250 spilled VGPRs
+						if (i == 3) __builtin_amdgcn_sched_barrier(0);
 					}
 				}
 		};
