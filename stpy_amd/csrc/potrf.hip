@@ -13,6 +13,7 @@
 // buffer.  inverse(L_cc) of every diagonal block is kept in `winv` for the triangular solves.
 #include <atomic>
 #include <map>
+#include <vector>
 #include <mutex>
 
 #include "common.h"
@@ -23,8 +24,13 @@ namespace stpy {
 // with 512 (measured 2 % faster end to end at N = 65 536); the solves keep 512 (see solve.hip)
 int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B runs)
 // stpy_tune key 18: the rows below a panel's diagonal block as one strip launch (solve.hip) instead of two products per 128 columns.
-// 0 (default): off; 2: only for panels factored with nothing else on the chip (the first one: no measurable difference); 1: every panel -- slower, the strip kernel's
-// 120-202 VGPRs wait for update workgroups to retire (tools/potrf_sweep.py 18=0|1: 34.8 -> 35.5 ms at N = 16 384, 1368 -> 1381 at 65 536)
+// 0 (default): off.  1: every panel, on the look-ahead stream -- the strip kernel's 120-202 VGPRs wait for update workgroups to retire.
+// 2: only the first panel (nothing else on the chip: no measurable difference).  3: the look-ahead stream factors only the panel's
+// diagonal block and the strip runs on the update's stream after the trailing update (with key 12 the whole chain then sits on the
+// reserved CUs).  All slower than 0 (tools/potrf_sweep.py "18=0|1|3;12=0|16384", ms at N = 16 384 / 32 768 / 65 536: 34.5 / 190.7 / 1376
+// against 35.5 / 193 / 1381 (1), 35.8 / 197.5 / 1403 (3), 37.8 / 203 / 1407 (3 + reserved)): in the kernel trace the diagonal-block
+// kernel alone is 21 of the 35 ms at N = 16 384 (165 us average beside the update, 58 us alone) whatever surrounds it, and keeping
+// the update off eight CUs costs more than that kernel gains.
 int g_potrf_strip = 0;
 // stpy_tune key 11 (0 = off, the default): blocks factored beside a trailing update take the 64-VGPR / four-wave form below.
 // Measured (tools/potrf_sweep.py, gpurun_out/potrf_sweep3.log): it is placed at once, as intended, but then RUNS 8x slower
@@ -722,11 +728,24 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 
 // Created on first use only (the mode is off by default, stpy_tune key 12): masked streams alive at process exit have been
 // seen to crash the profiler's finalisation.
+static std::vector<LookAhead*> g_la_masked;          // objects that own CU-masked streams (guarded by g_la_mutex)
+static void destroy_masked_streams()                 // atexit: registered after the HIP runtime's own handlers, so it runs before them
+{
+	std::lock_guard<std::mutex> lock(g_la_mutex);
+	for (LookAhead* la : g_la_masked) {
+		if (la->upd) (void)hipStreamDestroy(la->upd);
+		if (la->diag) (void)hipStreamDestroy(la->diag);
+		la->upd = la->diag = nullptr;
+	}
+	g_la_masked.clear();
+}
 static void lookahead_reserved_streams(LookAhead* la)
 {
 	std::lock_guard<std::mutex> lock(g_la_mutex);
 	if (la->upd || la->reserved_tried) return;
 	la->reserved_tried = true;
+	static bool registered = false;
+	if (!registered) { registered = true; (void)atexit(destroy_masked_streams); }
 	// "reserved" mode (potrf, mid-size trailing matrices): the trailing update runs on a stream masked OFF one CU per XCD and
 	// the diagonal-block kernel on a stream masked ONTO those eight CUs.  Mask bits are dealt round-robin over the eight XCCs
 	// (tools/cumask_probe.hip: bits 0-7 = se0.cu0 of xcc0..7; an XCC whose bits are all clear gets ALL its CUs, so no XCC is
@@ -741,8 +760,14 @@ static void lookahead_reserved_streams(LookAhead* la)
 		    hipEventCreateWithFlags(&la->ev_mode, hipEventDisableTiming) != hipSuccess) {
 			(void)hipGetLastError();
 			la->upd = la->diag = nullptr;
-		}
+		} else g_la_masked.push_back(la);
 	}
+}
+
+template <typename T>
+static bool potrf_panel_can_strip(int64_t n, int64_t k, int64_t kb, const T* A, int64_t lda, const T* winv, int64_t ldp)
+{
+	return kb % IB == 0 && kb <= 8 * IB && k + kb < n && n - k - kb < (1 << 30) && trsm_strip_ok(sizeof(T), A, lda, winv) && ldp % (int64_t)(16 / sizeof(T)) == 0;
 }
 
 // Factor the nb-wide panel whose first column is k (its columns already carry every update from
@@ -750,7 +775,8 @@ static void lookahead_reserved_streams(LookAhead* la)
 // panel workspace P (n x nb, leading dimension nb, rows indexed globally).
 template <typename T>
 static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* winv, T* P, int64_t ldp, int32_t* info, hipStream_t st,
-                        int gflags, hipEvent_t first_diag = nullptr, hipStream_t diag_st = nullptr, hipEvent_t ev_diag = nullptr, hipEvent_t ev_gemm = nullptr)
+                        int gflags, hipEvent_t first_diag = nullptr, hipStream_t diag_st = nullptr, hipEvent_t ev_diag = nullptr, hipEvent_t ev_gemm = nullptr,
+                        int strip_mode = -1)          // -1: by stpy_tune key 18; 0: per-block products over all rows; 1: strip launch on `st`; 2: rows below left to the caller
 {
 	// diag_st != nullptr ("reserved" mode): the 128 x 128 diagonal-block kernel runs on its own stream, which is masked onto
 	// CUs the trailing update cannot use, with an event hand-over in each direction; the panel GEMMs stay on `st`.
@@ -759,7 +785,10 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 	int rc;
 	// Rows below the panel's diagonal block: one strip launch after that block is factored (solve.hip: trsm_strip_kernel)
 	// instead of two products per 128 columns over all of them -- the chain of small kernels then only spans kb rows.
-	const bool strip = (g_potrf_strip == 1 || (g_potrf_strip == 2 && !(gflags & GEMM_BESIDE))) && kb % IB == 0 && kb <= 8 * IB && k + kb < n && n - k - kb < (1 << 30) && trsm_strip_ok(sizeof(T), A, lda, winv) && ldp % (int64_t)(16 / sizeof(T)) == 0;
+	const bool can_strip = potrf_panel_can_strip<T>(n, k, kb, A, lda, winv, ldp);
+	if (strip_mode < 0) strip_mode = (g_potrf_strip == 1 || g_potrf_strip == 3 || (g_potrf_strip == 2 && !(gflags & GEMM_BESIDE))) ? 1 : 0;
+	if (!can_strip) strip_mode = 0;
+	const bool strip = strip_mode != 0;
 	const int64_t rows_end = strip ? k + kb : n;           // the per-block chain below covers rows [c, rows_end)
 	for (int64_t c = k; c < k + kb; c += IB) {
 		const int64_t cb = (n - c < IB) ? (n - c) : IB;
@@ -785,7 +814,7 @@ static int factor_panel(int64_t n, int64_t k, int64_t kb, T* A, int64_t lda, T* 
 			if (rc) return rc;
 		}
 	}
-	if (strip) {
+	if (strip_mode == 1) {
 		const int64_t mb = n - k - kb;
 		ProfScope ps(TAG_PANEL_GEMM, (double)mb * (double)kb * (double)kb, st);
 		rc = trsm_strip<T>(mb, A + k * lda + k, lda, winv + (k / IB) * IB * IB, A + (k + kb) * lda + k, lda, P + (k + kb) * ldp, ldp, kb, st);
@@ -854,17 +883,23 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 			rc = gemm_nt<T>(n - r, nkb, wk, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, U);
 			if (rc) return rc;
 		}
+		// key 18 = 3: the look-ahead stream factors only the panel's nkb x nkb diagonal block (the latency-bound chain: diagonal-block
+		// kernels + small products over <= nkb rows); the rows below it are ONE strip launch on the update's stream once the trailing
+		// update has drained -- alone on the chip, at its stand-alone speed, instead of 2 x nkb/128 sliver products beside the update.
+		// Together with the reserved mode the WHOLE chain runs on the stream masked onto the reserved CUs (no per-block hand-over).
+		const bool defer = g_potrf_strip == 3 && potrf_panel_can_strip<T>(n, r, nkb, A, lda, winv, ldp);
+		hipStream_t chain = (reserve && defer) ? la->diag : side;
 		HIPCHK(hipEventRecord(la->col_ready, U));
-		HIPCHK(hipStreamWaitEvent(side, la->col_ready, 0));
+		HIPCHK(hipStreamWaitEvent(chain, la->col_ready, 0));
 		// A short trailing update cannot hide the panel chain, and the chain's first kernel -- one workgroup that needs
 		// 83 KiB of LDS -- is slowed down by the update's workgroups once they have flooded the chip (kernel trace,
 		// tools/potrf_only.py).  Below the threshold the update therefore starts only after that kernel has run.
 		const bool diag_first = !reserve && (n - r) <= g_potrf_diag_first_below;
 		const int pflags = gflags | ((n - r - nkb) >= g_potrf_beside_min ? GEMM_BESIDE : 0);
-		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, side, pflags, diag_first ? la->trail_done : nullptr,
-		                     reserve ? la->diag : nullptr, la->ev_diag, la->ev_gemm);
+		rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, chain, (reserve && defer) ? gflags : pflags, diag_first ? la->trail_done : nullptr,
+		                     (reserve && !defer) ? la->diag : nullptr, la->ev_diag, la->ev_gemm, defer ? 2 : -1);
 		if (rc) return rc;
-		HIPCHK(hipEventRecord(la->panel_done, side));
+		HIPCHK(hipEventRecord(la->panel_done, chain));
 		if (diag_first) HIPCHK(hipStreamWaitEvent(U, la->trail_done, 0));
 		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
 			const int64_t r2 = r + nkb;
@@ -873,6 +908,12 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 			if (rc) return rc;
 		}
 		HIPCHK(hipStreamWaitEvent(U, la->panel_done, 0));
+		if (defer) {
+			const int64_t mb = n - r - nkb;
+			ProfScope ps(TAG_PANEL_GEMM, (double)mb * (double)nkb * (double)nkb, U);
+			rc = trsm_strip<T>(mb, A + r * lda + r, lda, winv + (r / IB) * IB * IB, A + (r + nkb) * lda + r, lda, Pbuf[cur ^ 1] + (r + nkb) * ldp, ldp, nkb, U);
+			if (rc) return rc;
+		}
 		// the side stream may not start overwriting workspace `cur` (panel k+2) before this
 		// trailing update has finished reading it: it waits on the next col_ready, which is
 		// recorded on `U` after this update -- stream order (and ev_mode across a change of mode) gives that.

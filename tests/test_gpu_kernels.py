@@ -598,6 +598,34 @@ def test_trsm_many_rows_default_is_recursive(L):
 		assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_potrf_panel_strip_modes(L, mode, dtype, tol):
+	"""stpy_tune key 18: how the rows below a panel's diagonal block are solved -- two products per 128 columns beside the update (0),
+	one strip launch on the look-ahead stream (1; 2: first panel only), or one strip launch on the update's stream after the
+	trailing update (3).  Same factor and inverse blocks in every mode; aligned and ragged orders, a failing pivot reported alike."""
+	lib = L.load()
+	lib.stpy_tune(18, mode)
+	try:
+		for n, nb in ((2048 + 256, 512), (1500, 256), (4096, 0)):
+			rng = np.random.RandomState(n + 3)
+			K = spd(rng, n)
+			Ld, winv, info = run_potrf(L, K, nb, dtype)
+			assert info == 0
+			Lref = np.linalg.cholesky(K)
+			assert rel_err(np.tril(Ld.cpu().numpy().astype(np.float64)), Lref) < tol
+			W = winv.cpu().numpy().astype(np.float64).reshape(-1, 128, 128)
+			for bi in (0, (n + 127) // 128 - 1):
+				c, cb = bi * 128, min(128, n - bi * 128)
+				assert rel_err(W[bi][:cb, :cb], np.linalg.inv(Lref[c:c + cb, c:c + cb])) < tol * 100
+		K = spd(np.random.RandomState(9), 1536)
+		K[1100, 1100] = -1.0
+		_, _, info = run_potrf(L, K, 256, dtype)
+		assert info == 1101
+	finally:
+		lib.stpy_tune(18, 0)
+
+
 @pytest.mark.parametrize("strip", [512, 1024, 0, 1])
 def test_trsm_strip_leaf(L, strip):
 	"""fp64 recursive block solve with its 512- / 1024-column leaves as one strip launch each (stpy_tune key 17; 0 = the
