@@ -18,7 +18,7 @@ def collect(path, counter):
 
 def main():
 	fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-	g = lambda d: [(k, v) for k, v in d.items() if k.startswith("stpy::gemm_nt_kernel<double") or k.startswith("stpy::gemm_nt_dtv_kernel") or k.startswith("stpy::gemm_nt_k128_kernel") or k.startswith("stpy::gemm_nt_sliver_kernel")]
+	g = lambda d: [(k, v) for k, v in d.items() if k.startswith("stpy::gemm_nt_kernel<double") or k.startswith("stpy::gemm_nt_dtv_kernel") or k.startswith("stpy::gemm_nt_k128_kernel") or k.startswith("stpy::gemm_nt_sliver_kernel") or k.startswith("stpy::trsm_strip_kernel")]
 	launches = sum(v["dispatches"] for _, v in g(fetch))
 	f_bytes = sum(v["sum_KB"] for _, v in g(fetch)) * 1024.0
 	w_bytes = sum(v["sum_KB"] for _, v in g(write)) * 1024.0
