@@ -195,7 +195,8 @@ int stpy_gemm_nt_splitk(int dtype, int64_t m, int64_t n, int64_t k,
  * The same contraction on a window of a rank's LOCAL matrix under a 2-D block-cyclic distribution
  * (multi-GPU trailing update): distribution block nb_dist (multiple of 128), process grid pr x pc,
  * this rank (myr, myc); the window starts at local block (i0, j0).  A 128x128 tile in local block
- * (bi, bj) belongs to global block (I, J) = (bi*pr + myr, bj*pc + myc) and is skipped when I < J.
+ * (bi, bj) belongs to global block (I, J) = (bi*pr + myr, bj*pc + myc) and is skipped when I < J; inside a diagonal
+ * block (I == J) only the tiles on and below that block's own diagonal are touched (the symmetric update needs no more).
  */
 int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k,
                     const void* A, int64_t lda, const void* B, int64_t ldb,

@@ -223,6 +223,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		const int I = (ti / p.bc_nbt + p.bc_i0) * p.bc_pr + p.bc_myr;
 		const int J = (tj / p.bc_nbt + p.bc_j0) * p.bc_pc + p.bc_myc;
 		if (I < J) return;
+		if (I == J && (tj % p.bc_nbt) > (ti % p.bc_nbt)) return;          // diagonal distribution block: its lower tiles only (4.7 % of the flops at 64 blocks)
 	}
 
 	const int row0 = ti * BM, col0 = tj * BN;
@@ -636,6 +637,7 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 		const int I = (ti / p.bc_nbt + p.bc_i0) * p.bc_pr + p.bc_myr;
 		const int J = (tj / p.bc_nbt + p.bc_j0) * p.bc_pc + p.bc_myc;
 		if (I < J) return;
+		if (I == J && (tj % p.bc_nbt) > (ti % p.bc_nbt)) return;          // diagonal distribution block: its lower tiles only (4.7 % of the flops at 64 blocks)
 	}
 	const int row0 = ti * BM, col0 = tj * BN;
 	const int kbeg = p.kskip ? row0 : split * p.kchunk;

@@ -99,7 +99,7 @@ class CpuLocalOps:
 			for tj in range((n + IB - 1) // IB):
 				I = (ti // nbt + i0) * pr + myr
 				J = (tj // nbt + j0) * pc + myc
-				if I < J:
+				if I < J or (I == J and tj % nbt > ti % nbt):
 					continue
 				rs, cs = slice(ti * IB, min(m, ti * IB + IB)), slice(tj * IB, min(n, tj * IB + IB))
 				C[rs, cs] = prod[rs, cs] if mode == 0 else C[rs, cs] - prod[rs, cs]

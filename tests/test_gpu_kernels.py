@@ -220,7 +220,8 @@ def test_two_threads_two_streams(L):
 	(512, 512, 512, 512, 1, 1, 0, 0, 2, 2),         # one process: plain lower staircase at distribution-block granularity
 ])
 def test_gemm_nt_bc_staircase(L, m, n, k, nbd, pr, pc, myr, myc, i0, j0):
-	"""stpy_gemm_nt_bc: C -= A B^T on the 128x128 tiles whose distribution block (I, J) has I >= J, others untouched"""
+	"""stpy_gemm_nt_bc: C -= A B^T on the 128x128 tiles whose distribution block (I, J) has I > J, and on the lower tiles of the
+	diagonal blocks (I == J); all others untouched"""
 	rng = np.random.RandomState(m + n + k + myr + myc)
 	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
 	Ad, Bd, Cd = dev(A), dev(B), dev(C)
@@ -234,7 +235,7 @@ def test_gemm_nt_bc_staircase(L, m, n, k, nbd, pr, pc, myr, myc, i0, j0):
 			I = (ti // nbt + i0) * pr + myr
 			J = (tj // nbt + j0) * pc + myc
 			blk = (slice(ti * 128, min(m, ti * 128 + 128)), slice(tj * 128, min(n, tj * 128 + 128)))
-			if I >= J:
+			if I > J or (I == J and tj % nbt <= ti % nbt):
 				assert rel_err(out[blk], full[blk]) < 1e-13, (ti, tj)
 			else:
 				assert np.array_equal(out[blk], C[blk]), (ti, tj)
