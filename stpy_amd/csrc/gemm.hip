@@ -436,33 +436,22 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		T na4[4];
 #pragma unroll
 		for (int tn = 0; tn < 4; ++tn) na4[tn] = ns[wn * 64 + r16 + tn * 16];
-		auto apply = [&](auto KC) {
-			constexpr int KIND = decltype(KC)::value;
-#pragma unroll
-			for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-				for (int tn = 0; tn < 4; ++tn) {
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)], tab) + p.g_offset;
-						// four independent exp chains at a time cover the FMA latency and the LDS round trip of the table
-						// read (two measure the same: the epilogue is bound by instruction issue -- 17 VALU per element at
-						// ~7.5 cycles in this kernel -- not by latency); letting the scheduler interleave all 64 costs
-						// >250 spilled VGPRs
-						if (i == 3) __builtin_amdgcn_sched_barrier(0);
-					}
-				}
-		};
-		switch (p.g_kind) {
-		case STPY_K_SE: apply(std::integral_constant<int, STPY_K_SE>{}); break;
-		case STPY_K_MATERN32: apply(std::integral_constant<int, STPY_K_MATERN32>{}); break;
-		case STPY_K_MATERN52: apply(std::integral_constant<int, STPY_K_MATERN52>{}); break;
-		default: apply(std::integral_constant<int, STPY_K_LINEAR>{}); break;
-		}
-		if (p.g_combine != STPY_OUT_SET) {         // kernel algebra: out (+|*)= k, the old tile read 16 values at a time
-			const bool add = p.g_combine == STPY_OUT_ADD;
-#pragma unroll
-			for (int tm = 0; tm < 4; ++tm) {
+		// One 16-row slab of the wave's tile at a time: kernel function, algebra, diagonal term, then its stores -- so the stores of
+		// slab tm drain under the arithmetic of slab tm + 1.  (All the arithmetic first and 64 stores per lane at the end: 8.5 ms at
+		// N = 65 536 for 5.1 ms of arithmetic and 5.4 ms of HBM write; a wave stalled at the store queue issues nothing else.)
+		// Aligned tiles turn the slab through a wave-private LDS patch (behind the norms and the exp table) and store 16 bytes per
+		// lane, 512 (fp64) / 256 (fp32) contiguous bytes per row; ragged ones keep the element stores.
+		constexpr int PLD = 80, CHW = 16 / (int)sizeof(T), LPR = 64 / CHW, RPI = 64 / LPR;          // patch row stride 80: conflict-free writes
+		typedef T vst __attribute__((ext_vector_type(CHW)));
+		const bool wide = !GUARD && (((uintptr_t)p.C) & 15) == 0 && p.ldc % CHW == 0;
+		T* const patch = smem + 2 * BN + GRAM_TAB + wave * (16 * PLD);
+		const int prow = lane / LPR, pcol = (lane % LPR) * CHW;
+		const bool algebra = p.g_combine != STPY_OUT_SET, add = p.g_combine == STPY_OUT_ADD;
+		const bool on_diag = p.g_diag != T(0) && row0 == col0;          // tiles are 128-aligned: only diagonal tiles hold i == j
+		const bool no_store = (p.exp & 16) != 0;                        // timing ablation (stpy_tune key 1 = 16): the fill without its stores
+		auto finish_slab = [&](auto TM) __attribute__((always_inline)) {
+			constexpr int tm = decltype(TM)::value;          // (a compile-time index: a run-time one would put the accumulators into scratch)
+			if (algebra) {         // kernel algebra: out (+|*)= k, the old slab read 16 values at a time
 				T old[4][4];
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
@@ -479,18 +468,70 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 					for (int tn = 0; tn < 4; ++tn)
 						acc[tm][tn][i] = add ? old[tn][i] + acc[tm][tn][i] : old[tn][i] * acc[tm][tn][i];
-				__builtin_amdgcn_sched_barrier(0);
 			}
-		}
-		if (p.g_diag != T(0) && row0 == col0) {         // tiles are 128-aligned: only diagonal tiles hold i == j
-#pragma unroll
-			for (int tm = 0; tm < 4; ++tm)
+			if (on_diag) {
 #pragma unroll
 				for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
 					for (int i = 0; i < 4; ++i)
 						if (wm * 64 + tm * 16 + MM::crow(lane, i) == wn * 64 + r16 + tn * 16) acc[tm][tn][i] += p.g_diag;
+			}
+			if (no_store) {
+				if (acc[tm][0][0] + acc[tm][1][1] + acc[tm][2][2] + acc[tm][3][3] == T(12345.678)) ctile[0] = acc[tm][0][0];
+			} else if (wide) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn) patch[MM::crow(lane, i) * PLD + tn * 16 + r16] = acc[tm][tn][i];
+#pragma unroll
+				for (int q = 0; q < 16 / RPI; ++q) {
+					const int rr = q * RPI + prow;
+					const vst v = *(const vst*)&patch[rr * PLD + pcol];
+					__builtin_nontemporal_store(v, (vst*)(ctile + ((unsigned)(wm * 64 + tm * 16 + rr) * ldc32 + (unsigned)(wn * 64 + pcol))));
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
+					T* const crow = ctile + ((unsigned)lr * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn) {
+						if (GUARD && (row0 + lr >= p.m || col0 + wn * 64 + r16 + tn * 16 >= p.n)) continue;
+						// streaming output (far larger than the caches): bypass the L2 allocation so that the operand tiles the
+						// next workgroups re-read stay resident
+						__builtin_nontemporal_store(acc[tm][tn][i], &crow[tn * 16]);
+					}
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		auto slab = [&](auto KC, auto TM) __attribute__((always_inline)) {
+			constexpr int KIND = decltype(KC)::value, tm = decltype(TM)::value;
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)], tab) + p.g_offset;
+					// four independent exp chains at a time cover the FMA latency and the LDS round trip of the table
+					// read; letting the scheduler interleave all 64 costs >250 spilled VGPRs
+					if (i == 3) __builtin_amdgcn_sched_barrier(0);
+				}
+			}
+			finish_slab(TM);
+		};
+		auto apply = [&](auto KC) __attribute__((always_inline)) {
+			slab(KC, std::integral_constant<int, 0>{});
+			slab(KC, std::integral_constant<int, 1>{});
+			slab(KC, std::integral_constant<int, 2>{});
+			slab(KC, std::integral_constant<int, 3>{});
+		};
+		switch (p.g_kind) {
+		case STPY_K_SE: apply(std::integral_constant<int, STPY_K_SE>{}); break;
+		case STPY_K_MATERN32: apply(std::integral_constant<int, STPY_K_MATERN32>{}); break;
+		case STPY_K_MATERN52: apply(std::integral_constant<int, STPY_K_MATERN52>{}); break;
+		default: apply(std::integral_constant<int, STPY_K_LINEAR>{}); break;
 		}
+		return;          // (no second copy in this mode)
 	}
 
 	// ---- evidence-gradient weight (mode 4): H = (w K^-1 - alpha alpha^T) o F, in place over K^-1 (or K^-1 read from C2)
@@ -560,7 +601,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 				if (SUB && DMA) acc[tm][tn][i] = -acc[tm][tn][i];
 				// streaming outputs (embedding, Gram matrix: far larger than the caches) bypass the L2 allocation
 				// so that the operand tiles the next workgroups re-read stay resident
-				if constexpr (EPI == 2 || EPI == 3) __builtin_nontemporal_store(acc[tm][tn][i], &crow[tn * 16]);
+				if constexpr (EPI == 2) __builtin_nontemporal_store(acc[tm][tn][i], &crow[tn * 16]);
 				else crow[tn * 16] = acc[tm][tn][i];
 			}
 		}

@@ -8,6 +8,8 @@ from stpy_amd import _lib as L
 lib = L.load()
 dev = torch.device("cuda:0")
 KINDS = {"SE": 0, "Matern-3/2": 2, "Matern-5/2": 3}
+if len(sys.argv) > 1:
+	lib.stpy_tune(1, int(sys.argv[1]))          # timing ablations of the GEMM kernel (16: the fill without its stores)
 for n in (32768, 65536):
 	d = 16
 	x = torch.rand(n, d, dtype=torch.float64, device=dev) * 2 - 1
