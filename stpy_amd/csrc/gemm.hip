@@ -123,30 +123,33 @@ __device__ __forceinline__ double gram_exp(double x)
 __device__ __forceinline__ float gram_exp(float x) { return __expf(x); }
 // Table-assisted form for the fused Gram epilogue, where the 20 instructions above made the fill VALU-bound (32 fp64 instructions
 // per element = a 4.9 TB/s ceiling, profiles/r02_a_gram_rff_pmc.json):  x = (k / 256) ln2 + r with |r| <= ln2 / 512, so
-// e^x = 2^(k >> 8) * tab[k & 255] * (1 + r + r^2/2 + r^3/6 + r^4/24)  (truncation 4e-17) -- 12 fp64 instructions, two integer ones
+// e^x = 2^(k >> 8) * tab[k & 255] * (1 + r + r^2/2 + r^3/6 + r^4/24)  (truncation 4e-17) -- 11 fp64 instructions, two integer ones
 // and an LDS read.  tab[i] = 2^(i/256): 2 KiB of LDS filled by the workgroup with the function above.
 constexpr int GRAM_TAB = 256;
 __device__ __forceinline__ double gram_exp_tab(double x, const double* tab)
 {
 	x = fmax(x, -745.0);
-	const double k = rint(x * 369.3299304675746);       // 256 / ln2
+	// k = rint(x * 256 / ln2) by the magic-number addition (round-to-nearest puts the integer into the low mantissa bits, two's
+	// complement in the low word): one FMA + one subtraction instead of multiply, round and convert
+	const double kd = fma(x, 369.3299304675746, 0x1.8p52);
+	const int ki = __double2loint(kd);
+	const double k = kd - 0x1.8p52;
 	double r = fma(-k, 0x1.62e42ffp-9, x);               // ln2 / 256 = hi + lo, hi with 29 significant bits: k * hi is exact
 	r = fma(-k, -1.6409824502660487e-13, r);
 	double q = fma(r, 4.1666666666666664e-02, 1.6666666666666666e-01);
 	q = fma(q, r, 0.5);
 	q = fma(q, r, 1.0);
 	q *= r;                                               // e^r - 1
-	const int ki = (int)k;
 	const double t = tab[ki & (GRAM_TAB - 1)];
 	return ldexp(fma(t, q, t), ki >> 8);
 }
 __device__ __forceinline__ float gram_exp_tab(float x, const float*) { return __expf(x); }
 
-// hna, hnb: MINUS HALF the squared norms (so the SE exponent is two additions away from the accumulator); tab: gram_exp_tab's table
-template <typename T, int KIND> __device__ __forceinline__ T gram_value(T acc, T hna, T hnb, const T* tab)
+// x: -0.5 |a - b|^2 straight from the accumulator (the contraction STARTS from -(|a|^2 + |b|^2) / 2, see the accumulator set-up of
+// the mode-3 kernel); tab: gram_exp_tab's table
+template <typename T, int KIND> __device__ __forceinline__ T gram_value(T x, const T* tab)
 {
-	if (KIND == STPY_K_LINEAR) return acc;
-	const T x = (acc + hna) + hnb;                                   // -0.5 |a - b|^2
+	if (KIND == STPY_K_LINEAR) return x;                             // (started from zero: the plain dot product)
 	if (KIND == STPY_K_SE) return gram_exp_tab(x, tab);              // no clamp, as kernels.py:395
 	const T rr = sqrt(fmax(T(-2) * x, T(0)));
 	if (KIND == STPY_K_MATERN32) { const T r = rr * T(1.7320508075688772935); return (T(1) + r) * gram_exp_tab(-r, tab); }
@@ -326,6 +329,18 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	v4 acc[4][4];
 	T* const ctile = p.C + (int64_t)split * p.split_stride + (int64_t)row0 * p.ldc + col0;
 	const unsigned ldc32 = (unsigned)p.ldc;
+	// Gram mode: the contraction starts from -(|a_i|^2 + |b_j|^2) / 2, so the accumulator ends as -|a_i - b_j|^2 / 2 and the
+	// epilogue spends no instruction on the norm expansion (zero for the linear kernel: the plain dot product)
+	T gram_ha[4] = {T(0), T(0), T(0), T(0)};
+	if constexpr (EPI == 3) {
+		if (p.g_kind != STPY_K_LINEAR) {
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) {
+				const int col = col0 + wn * 64 + tn * 16 + r16;
+				gram_ha[tn] = T(-0.5) * p.g_na[GUARD ? min(col, p.n - 1) : col];
+			}
+		}
+	}
 #pragma unroll
 	for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -333,9 +348,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			const int lr = wm * 64 + tm * 16 + MM::crow(lane, i);
 			const int lr_c = GUARD ? min(lr, p.m - 1 - row0) : lr;
 			const T* const crow = ctile + ((unsigned)lr_c * ldc32 + (unsigned)(wn * 64 + r16));
+			T gram_hb = T(0);
+			if constexpr (EPI == 3) { if (p.g_kind != STPY_K_LINEAR) gram_hb = T(-0.5) * p.g_nb[row0 + lr_c]; }
 #pragma unroll
 			for (int tn = 0; tn < 4; ++tn) {
-				T v = T(0);
+				T v = (EPI == 3) ? gram_ha[tn] + gram_hb : T(0);
 				if (SUB) {      // unconditional loads (clamped address when ragged): no per-element branches
 					if (!GUARD) v = crow[tn * 16];
 					else v = ctile[(unsigned)lr_c * ldc32 + (unsigned)min(wn * 64 + r16 + tn * 16, p.n - 1 - col0)];
@@ -425,17 +442,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	// the epilogue 130 KB of branchy code that no longer fit the instruction cache); the kernel
 	// algebra (+, *) and the diagonal term are separate, rarely taken passes.
 	if constexpr (EPI == 3) {
-		// the tile's 128 + 128 norms go through LDS (the staging buffers are free after the K loop):
-		// holding them in registers next to the accumulators does not fit
-		T* const ns = smem;
-		T* const tab = ns + 2 * BN;
-		if (tid < BN) { const int col = col0 + tid; ns[tid] = T(-0.5) * p.g_na[GUARD ? min(col, p.n - 1) : col]; }
-		else { const int row = row0 + tid - BN; ns[tid] = T(-0.5) * p.g_nb[GUARD ? min(row, p.m - 1) : row]; }
+		// the exp table lives in LDS (the staging buffers are free after the K loop)
+		T* const tab = smem + 2 * BN;
+		__syncthreads();          // every wave is past its last read of the staging buffers
 		if constexpr (sizeof(T) == 8) tab[tid] = gram_exp(T(tid) * T(0.693147180559945309417 / GRAM_TAB));          // 256 threads, 256 entries
 		__syncthreads();
-		T na4[4];
-#pragma unroll
-		for (int tn = 0; tn < 4; ++tn) na4[tn] = ns[wn * 64 + r16 + tn * 16];
 		// One 16-row slab of the wave's tile at a time: kernel function, algebra, diagonal term, then its stores -- so the stores of
 		// slab tm drain under the arithmetic of slab tm + 1.  (All the arithmetic first and 64 stores per lane at the end: 8.5 ms at
 		// N = 65 536 for 5.1 ms of arithmetic and 5.4 ms of HBM write; a wave stalled at the store queue issues nothing else.)
@@ -511,7 +522,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 			for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
-					acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], na4[tn], ns[BN + wm * 64 + tm * 16 + MM::crow(lane, i)], tab) + p.g_offset;
+					acc[tm][tn][i] = p.g_kappa * gram_value<T, KIND>(acc[tm][tn][i], tab) + p.g_offset;
 					// four independent exp chains at a time cover the FMA latency and the LDS round trip of the table
 					// read; letting the scheduler interleave all 64 costs >250 spilled VGPRs
 					if (i == 3) __builtin_amdgcn_sched_barrier(0);
