@@ -215,6 +215,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	} else {
 		si = S / p.nst_n;
 		sj = S - si * p.nst_n;
+		// block-cyclic staircase: the super-tiles above it are empty, and with consecutive S going to consecutive XCDs a plain
+		// row-major order gives XCD x the super-tile COLUMNS x, x + 8, ... -- the leftmost (longest) columns all to XCD 0 (80 against
+		// 52 super-tiles at 32 block rows).  Rotating each row by its index spreads every column over all XCDs.
+		if (p.bc_nbt > 0) { sj += si % p.nst_n; if (sj >= p.nst_n) sj -= p.nst_n; }
 	}
 	// (the tile index comes out of VALU arithmetic; readfirstlane tells the compiler it is uniform,
 	// so tile bases live in SGPRs and per-lane addresses stay 32-bit offsets)
@@ -680,6 +684,10 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 	} else {
 		si = S / p.nst_n;
 		sj = S - si * p.nst_n;
+		// block-cyclic staircase: the super-tiles above it are empty, and with consecutive S going to consecutive XCDs a plain
+		// row-major order gives XCD x the super-tile COLUMNS x, x + 8, ... -- the leftmost (longest) columns all to XCD 0 (80 against
+		// 52 super-tiles at 32 block rows).  Rotating each row by its index spreads every column over all XCDs.
+		if (p.bc_nbt > 0) { sj += si % p.nst_n; if (sj >= p.nst_n) sj -= p.nst_n; }
 	}
 	const int ti = __builtin_amdgcn_readfirstlane(si * p.st_m + w / p.st_n);
 	const int tj = __builtin_amdgcn_readfirstlane(sj * p.st_n + w % p.st_n);
