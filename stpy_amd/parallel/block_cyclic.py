@@ -260,6 +260,17 @@ class DistributedGaussianProcess:
 				raise
 			# (raised identically on every rank before any communicator exists, so the retry stays collective)
 			self.row_groups, self.col_groups = make_groups({})
+		# RCCL creates a communicator at the FIRST collective of a group.  Do that here, in one fixed order (own process row, then
+		# own process column: the row groups are disjoint, so are the column groups -- no cyclic wait), instead of in the middle of
+		# the first panel step where ranks reach their groups at different points of the schedule.
+		if dist.get_backend() == "nccl" and self.world > 1:
+			token = torch.zeros(1, dtype=torch.float32, device=self.ops.device)
+			if self.Pc > 1:
+				dist.all_reduce(token, group=self.row_groups[self.myr])
+			if self.Pr > 1:
+				dist.all_reduce(token, group=self.col_groups[self.myc])
+			dist.all_reduce(token)
+			torch.cuda.synchronize()
 
 	# ------------------------------------------------------------------ index arithmetic
 	def _rank_of(self, r, c):
