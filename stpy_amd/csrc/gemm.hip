@@ -40,6 +40,7 @@ int g_gemm_k128 = 768;           // K = 128 products with at most this many 64 x
 int g_gemm_exp = 0;        // timing experiments only (results are wrong when != 0)
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
 
+constexpr int BC_MAX_ROWS = 64;
 template <typename T>
 struct GemmArgs {
 	const T* A; const T* B; T* C; T* C2;
@@ -70,6 +71,9 @@ struct GemmArgs {
 	// the local matrix = global block (I, J) = (.. * bc_pr + bc_myr, .. * bc_pc + bc_myc); tiles
 	// with I < J (strictly above the global diagonal) are skipped.  bc_nbt == 0: off.
 	int bc_nbt, bc_pr, bc_pc, bc_myr, bc_myc, bc_i0, bc_j0;
+	// compact enumeration of the staircase: bc_pref[si] = number of non-empty super-tiles in super-tile rows < si (rows are
+	// non-empty from the left); bc_compact == 0: the full rectangle is enumerated and empty super-tiles exit at once
+	int bc_compact; int bc_pref[BC_MAX_ROWS + 1];
 	int exp;                 // timing experiments (0 in production)
 	// split-K (few output tiles, long K): the super-tile range is enumerated ksplit times; pass s
 	// contracts K range [s*kchunk, (s+1)*kchunk) into the partial result at C + s*split_stride
@@ -212,12 +216,19 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		while ((si + 1) * (si + 2) / 2 <= S) ++si;
 		while (si * (si + 1) / 2 > S) --si;
 		sj = S - si * (si + 1) / 2;
+	} else if (p.bc_compact) {
+		// block-cyclic staircase, compact: only the super-tiles that hold work are enumerated (host-built prefix table in the
+		// kernel arguments).  Enumerating the rectangle and letting the empty ones exit costs 13-32 % (tools/bc_vs_tri.py): workgroups
+		// are dispatched in order and each goes to XCD b % 8, so an XCD that drew empty super-tiles idles behind the others' full ones.
+		int lo = 0, hi = p.nst_m;                 // largest si with bc_pref[si] <= S
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.bc_pref[mid] <= S) lo = mid; else hi = mid; }
+		si = lo;
+		sj = S - p.bc_pref[si];
 	} else {
 		si = S / p.nst_n;
 		sj = S - si * p.nst_n;
-		// block-cyclic staircase: the super-tiles above it are empty, and with consecutive S going to consecutive XCDs a plain
-		// row-major order gives XCD x the super-tile COLUMNS x, x + 8, ... -- the leftmost (longest) columns all to XCD 0 (80 against
-		// 52 super-tiles at 32 block rows).  Rotating each row by its index spreads every column over all XCDs.
+		// (block-cyclic staircase on more super-tile rows than the prefix table holds: rectangle, rows rotated by their index so that
+		// every XCD gets a mix of long and short columns)
 		if (p.bc_nbt > 0) { sj += si % p.nst_n; if (sj >= p.nst_n) sj -= p.nst_n; }
 	}
 	// (the tile index comes out of VALU arithmetic; readfirstlane tells the compiler it is uniform,
@@ -681,12 +692,19 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 		while ((si + 1) * (si + 2) / 2 <= S) ++si;
 		while (si * (si + 1) / 2 > S) --si;
 		sj = S - si * (si + 1) / 2;
+	} else if (p.bc_compact) {
+		// block-cyclic staircase, compact: only the super-tiles that hold work are enumerated (host-built prefix table in the
+		// kernel arguments).  Enumerating the rectangle and letting the empty ones exit costs 13-32 % (tools/bc_vs_tri.py): workgroups
+		// are dispatched in order and each goes to XCD b % 8, so an XCD that drew empty super-tiles idles behind the others' full ones.
+		int lo = 0, hi = p.nst_m;                 // largest si with bc_pref[si] <= S
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.bc_pref[mid] <= S) lo = mid; else hi = mid; }
+		si = lo;
+		sj = S - p.bc_pref[si];
 	} else {
 		si = S / p.nst_n;
 		sj = S - si * p.nst_n;
-		// block-cyclic staircase: the super-tiles above it are empty, and with consecutive S going to consecutive XCDs a plain
-		// row-major order gives XCD x the super-tile COLUMNS x, x + 8, ... -- the leftmost (longest) columns all to XCD 0 (80 against
-		// 52 super-tiles at 32 block rows).  Rotating each row by its index spreads every column over all XCDs.
+		// (block-cyclic staircase on more super-tile rows than the prefix table holds: rectangle, rows rotated by their index so that
+		// every XCD gets a mix of long and short columns)
 		if (p.bc_nbt > 0) { sj += si % p.nst_n; if (sj >= p.nst_n) sj -= p.nst_n; }
 	}
 	const int ti = __builtin_amdgcn_readfirstlane(si * p.st_m + w / p.st_n);
@@ -1246,6 +1264,28 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	p.nst_m = (p.tiles_m + p.st_m - 1) / p.st_m;
 	p.nst_n = (p.tiles_n + p.st_n - 1) / p.st_n;
 	p.nsuper = p.tri ? p.nst_m * (p.nst_m + 1) / 2 : p.nst_m * p.nst_n;
+	p.bc_compact = 0;
+	if (p.bc_nbt > 0 && p.nst_m <= BC_MAX_ROWS && ksplit <= 1) {
+		// a tile is needed iff its global block (I, J) has I > J, or I == J and it lies on / below that block's own diagonal; along a
+		// row the needed tiles are a prefix, so a super-tile row's count follows from its LAST tile row and each column's FIRST tile
+		auto needed = [&](int ti, int tj) {
+			const int I = (ti / p.bc_nbt + p.bc_i0) * p.bc_pr + p.bc_myr, J = (tj / p.bc_nbt + p.bc_j0) * p.bc_pc + p.bc_myc;
+			return I > J || (I == J && (tj % p.bc_nbt) <= (ti % p.bc_nbt));
+		};
+		int acc = 0;
+		for (int si = 0; si < p.nst_m; ++si) {
+			p.bc_pref[si] = acc;
+			int ti = si * p.st_m + p.st_m - 1;
+			if (ti >= p.tiles_m) ti = p.tiles_m - 1;
+			int cnt = 0;
+			while (cnt < p.nst_n && needed(ti, cnt * p.st_n)) ++cnt;
+			acc += cnt;
+		}
+		p.bc_pref[p.nst_m] = acc;
+		p.nsuper = acc;
+		p.bc_compact = 1;
+		if (acc == 0) return 0;          // nothing below the staircase in this window
+	}
 	const int64_t nblocks = (int64_t)(((int64_t)p.nsuper * p.ksplit + 7) / 8) * 512;
 	if (nblocks > INT32_MAX) { set_error("gemm_nt: grid too large"); return -2; }
 	// Workgroups of one launch all take the same time, so the two that share a CU would reach
