@@ -365,6 +365,7 @@ void stpy_tune(int key, int value)
 	if (key == 16) g_trsv_flow = value;
 	if (key == 18) g_potrf_strip = value;
 	if (key == 19) g_rff_wgs = value;
+	if (key == 20) g_gemm_tri_diag_last = value;
 	if (key == 17) g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0;
 }
 
@@ -392,6 +393,7 @@ int stpy_tune_get(int key)
 	case 17: return g_trsm_strip;
 	case 18: return g_potrf_strip;
 	case 19: return g_rff_wgs;
+	case 20: return g_gemm_tri_diag_last;
 	default: return -1;
 	}
 }

@@ -34,6 +34,8 @@ constexpr int BM = 128, BN = 128, NTHREADS = 256;
 // the LDS-DMA pieces and the swizzle
 template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof(T); };
 int g_gemm_stagger = 40000;    // first-round offset (cycles) between the two workgroups of a CU in launches of >= 4096 tiles (stpy_tune key 0; 0 = off, 1 = half a tile)
+int g_gemm_tri_diag_last = 0;  // stpy_tune key 20: lower-triangular launches enumerate their diagonal super-tiles last (0 = row-major triangle, the default:
+                               // tools/potrf_sweep.py "20=0|1" shows no difference at any size -- 1370.07 vs 1370.03 ms at N = 65 536)
 int g_gemm_dtv = 1;            // A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
 int g_gemm_dtv_min_k = 64;
 int g_gemm_k128 = 768;           // K = 128 products with at most this many 64 x 64 tiles take the one-volley kernel (stpy_tune key 8; 0 = never)
@@ -211,7 +213,18 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		if (split >= p.ksplit) return;
 	} else if (S >= p.nsuper) return;
 	int si, sj;
-	if (p.tri) {
+	if (p.tri == 2) {
+		// lower triangle, the DIAGONAL super-tiles (36 of 64 tiles) last, so that they form dispatch rounds of equal weight (experiment,
+		// see g_gemm_tri_diag_last: unlike the empty super-tiles of the block-cyclic staircase they cost nothing measurable in place)
+		const int noff = p.nst_m * (p.nst_m - 1) / 2;
+		if (S >= noff) { si = sj = S - noff; }
+		else {
+			si = (int)((sqrt(8.0 * (double)S + 1.0) + 1.0) * 0.5);          // strict lower triangle: S = si (si - 1) / 2 + sj, sj < si
+			while (si * (si + 1) / 2 <= S) ++si;
+			while (si * (si - 1) / 2 > S) --si;
+			sj = S - si * (si - 1) / 2;
+		}
+	} else if (p.tri) {
 		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
 		while ((si + 1) * (si + 2) / 2 <= S) ++si;
 		while (si * (si + 1) / 2 > S) --si;
@@ -687,7 +700,18 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 		if (split >= p.ksplit) return;
 	} else if (S >= p.nsuper) return;
 	int si, sj;
-	if (p.tri) {
+	if (p.tri == 2) {
+		// lower triangle, the DIAGONAL super-tiles (36 of 64 tiles) last, so that they form dispatch rounds of equal weight (experiment,
+		// see g_gemm_tri_diag_last: unlike the empty super-tiles of the block-cyclic staircase they cost nothing measurable in place)
+		const int noff = p.nst_m * (p.nst_m - 1) / 2;
+		if (S >= noff) { si = sj = S - noff; }
+		else {
+			si = (int)((sqrt(8.0 * (double)S + 1.0) + 1.0) * 0.5);          // strict lower triangle: S = si (si - 1) / 2 + sj, sj < si
+			while (si * (si + 1) / 2 <= S) ++si;
+			while (si * (si - 1) / 2 > S) --si;
+			sj = S - si * (si - 1) / 2;
+		}
+	} else if (p.tri) {
 		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
 		while ((si + 1) * (si + 2) / 2 <= S) ++si;
 		while (si * (si + 1) / 2 > S) --si;
@@ -1248,7 +1272,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		p.C = split_work; p.ldc = n;
 	}
 	p.exp = g_gemm_exp;
-	p.tri = (lower_only && m == n && !bc) ? 1 : 0;
+	p.tri = (lower_only && m == n && !bc) ? (g_gemm_tri_diag_last ? 2 : 1) : 0;
 	p.bc_nbt = 0; p.bc_pr = p.bc_pc = 1; p.bc_myr = p.bc_myc = p.bc_i0 = p.bc_j0 = 0;
 	if (bc) {
 		if (bc->nb_dist <= 0 || bc->nb_dist % BM != 0) { set_error("gemm_nt: block-cyclic block must be a positive multiple of %d", BM); return -13; }
