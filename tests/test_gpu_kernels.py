@@ -627,24 +627,27 @@ def test_potrf_panel_strip_modes(L, mode, dtype, tol):
 		lib.stpy_tune(18, 0)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 3e-4)])
 @pytest.mark.parametrize("strip", [512, 1024, 0, 1])
-def test_trsm_strip_leaf(L, strip):
-	"""fp64 recursive block solve with its 512- / 1024-column leaves as one strip launch each (stpy_tune key 17; 0 = the
-	three-launch leaves): same X as scipy for n a power of two, n with a ragged tail, and rows 16-aligned but not 128-aligned"""
+def test_trsm_strip_leaf(L, strip, dtype, tol):
+	"""recursive block solve with its leaves (up to 512 / 1024 columns) as one strip launch each (stpy_tune key 17; 0 = the
+	three-launch leaves): same X as scipy for n a power of two, n with a ragged tail, row counts that are / are not multiples of
+	the strip's 16 rows (the kernel guards the rest), a single row; fp64 and fp32"""
 	lib = L.load()
 	lib.stpy_tune(17, strip)
 	lib.stpy_tune(5, 4)          # recursive form whatever the row count
+	code = L.dtype_code(dtype)
 	try:
-		for n, m in ((2048, 2048), (1536 + 70, 144), (1024, 16)):
+		for n, m in ((2048, 2048), (1536 + 70, 144), (1024, 16), (640, 100), (384, 1), (896, 333)):
 			rng = np.random.RandomState(n + m + 1)
 			K = spd(rng, n)
-			Ld, winv, info = run_potrf(L, K, 0)
+			Ld, winv, info = run_potrf(L, K, 0, dtype)
 			assert info == 0
 			B = rng.normal(size=(m, n))
-			Bd = dev(B)
-			L.check(lib.stpy_trsm_right_lt(L.F64, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, 0, 0, None, 0, L.stream_ptr()), "trsm")
+			Bd = dev(B, dtype)
+			L.check(lib.stpy_trsm_right_lt(code, m, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(Bd), n, 0, 0, None, 0, L.stream_ptr()), "trsm")
 			Xref = sla.solve_triangular(np.linalg.cholesky(K), B.T, lower=True).T
-			assert rel_err(Bd.cpu().numpy(), Xref) < 1e-11
+			assert rel_err(Bd.cpu().numpy().astype(np.float64), Xref) < tol, (n, m)
 	finally:
 		lib.stpy_tune(17, 1)
 		lib.stpy_tune(5, 0)
