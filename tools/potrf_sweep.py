@@ -1,5 +1,5 @@
 """Interleaved A/B of stpy_potrf policies in ONE process (same buffers, same clocks): stpy_tune key / value pairs against
-the defaults, per matrix order.   usage: python tools/potrf_sweep.py "n1,n2,.." "key=v1|v2|..;key=..." [nb]
+the defaults, per matrix order.   usage: python tools/potrf_sweep.py "n1,n2,.." "key=v1|v2|..;key=..." [nb] [f32]
 e.g.  python tools/potrf_sweep.py 8192,16384,32768 "10=0|6144|1000000;7=0|8192" """
 import itertools
 import sys
@@ -21,22 +21,25 @@ def main():
 		k, vs = part.split("=")
 		axes.append((int(k), [int(v) for v in vs.split("|")]))
 	nb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+	dt = torch.float32 if len(sys.argv) > 4 and sys.argv[4] == "f32" else torch.float64
+	code = L.dtype_code(dt)
+	esz = 4 if dt == torch.float32 else 8
 	defaults = {k: int(lib.stpy_tune_get(k)) for k, _ in axes}
 	for n in ns:
 		d = 16
-		x = torch.rand(n, d, dtype=torch.float64, device=dev) * 2 - 1
-		il = torch.full((d,), 0.25, dtype=torch.float64, device=dev)
-		K = torch.empty(n, n, dtype=torch.float64, device=dev)
-		winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, device=dev)
-		work = torch.empty(max(int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)), 2 * n * 1024 * 8), dtype=torch.uint8, device=dev)          # (widest panel any policy picks)
+		x = torch.rand(n, d, dtype=dt, device=dev) * 2 - 1
+		il = torch.full((d,), 0.25, dtype=dt, device=dev)
+		K = torch.empty(n, n, dtype=dt, device=dev)
+		winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=dt, device=dev)
+		work = torch.empty(max(int(lib.stpy_potrf_workspace_bytes(code, n, nb)), 2 * n * 2048 * esz), dtype=torch.uint8, device=dev)          # (widest panel any policy picks)
 		info = torch.zeros(1, dtype=torch.int32, device=dev)
-		ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, d)), dtype=torch.uint8, device=dev)
+		ws = torch.empty(int(lib.stpy_gram_workspace_bytes(code, n, n, d)), dtype=torch.uint8, device=dev)
 
 		def gram():
-			L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, d, L.ptr(x), n, d, d, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()), "gram")
+			L.check(lib.stpy_gram(0, code, L.ptr(x), n, d, L.ptr(x), n, d, d, None, L.ptr(il), 1.0, 0.0, 0.01 if esz == 8 else 0.1, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()), "gram")
 
 		def potrf():
-			L.check(lib.stpy_potrf(L.F64, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
+			L.check(lib.stpy_potrf(code, n, L.ptr(K), n, L.ptr(winv), winv.numel(), L.ptr(work), work.numel(), nb, 0, L.ptr(info), L.stream_ptr()), "potrf")
 		combos = list(itertools.product(*[vs for _, vs in axes])) or [()]
 		best = {c: 1e9 for c in combos}
 		for rnd in range(4):
