@@ -366,6 +366,7 @@ void stpy_tune(int key, int value)
 	if (key == 18) g_potrf_strip = value;
 	if (key == 19) g_rff_wgs = value;
 	if (key == 20) g_gemm_tri_diag_last = value;
+	if (key == 21) g_potrf_serial_below = value;
 	if (key == 17) g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0;
 }
 
@@ -394,6 +395,7 @@ int stpy_tune_get(int key)
 	case 18: return g_potrf_strip;
 	case 19: return g_rff_wgs;
 	case 20: return g_gemm_tri_diag_last;
+	case 21: return g_potrf_serial_below;
 	default: return -1;
 	}
 }

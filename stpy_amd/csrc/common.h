@@ -112,7 +112,7 @@ inline bool trsm_is_recursive(size_t elem, int64_t m, bool upper_rhs)
 template <typename T>
 int trsm_strip(int64_t m, const T* Ld, int64_t ldl, const T* W, T* X, int64_t ldx, T* X2, int64_t ldx2, int64_t w, hipStream_t st);
 bool trsm_strip_ok(size_t elem, const void* L, int64_t ldl, const void* winv);
-extern int g_potrf_strip, g_rff_wgs, g_gemm_tri_diag_last;
+extern int g_potrf_strip, g_rff_wgs, g_gemm_tri_diag_last, g_potrf_serial_below;
 extern int g_potrf_diag_first_below, g_potrf_beside_min, g_potrf_reserve_below, g_potrf_reserve_above;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);

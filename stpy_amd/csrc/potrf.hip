@@ -32,6 +32,8 @@ int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B 
 // kernel alone is 21 of the 35 ms at N = 16 384 (165 us average beside the update, 58 us alone) whatever surrounds it, and keeping
 // the update off eight CUs costs more than that kernel gains.
 int g_potrf_strip = 0;
+int g_potrf_serial_below = 0;          // stpy_tune key 21 (see potrf()): no look-ahead below this many remaining rows.  Off: the fully serial
+                                       // order costs 42.4 ms at N = 16 384 against 35.2 overlapped (the chain ALONE is ~170 us per 128-block at that height)
 // stpy_tune key 11 (0 = off, the default): blocks factored beside a trailing update take the 64-VGPR / four-wave form below.
 // Measured (tools/potrf_sweep.py, gpurun_out/potrf_sweep3.log): it is placed at once, as intended, but then RUNS 8x slower
 // beside the real update than alone (730-770 us against 94 us in the kernel trace) and loses to the eight-wave kernel that
@@ -888,6 +890,23 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		// update has drained -- alone on the chip, at its stand-alone speed, instead of 2 x nkb/128 sliver products beside the update.
 		// Together with the reserved mode the WHOLE chain runs on the stream masked onto the reserved CUs (no per-block hand-over).
 		const bool defer = g_potrf_strip == 3 && potrf_panel_can_strip<T>(n, r, nkb, A, lda, winv, ldp);
+		// key 21: below this many remaining rows no look-ahead at all -- the whole trailing update first, then the panel on the same
+		// stream, each alone on the chip (beside the update the chain runs 3-5x slower, and a short update cannot hide it anyway)
+		const bool serial = !reserve && (n - r) <= g_potrf_serial_below;
+		if (serial) {
+			if (r + nkb < n) {
+				const int64_t r2 = r + nkb;
+				ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, U);
+				rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, U);
+				if (rc) return rc;
+			}
+			rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, U, gflags);
+			if (rc) return rc;
+			cur ^= 1;
+			k = r;
+			wk = nkb;
+			continue;
+		}
 		hipStream_t chain = (reserve && defer) ? la->diag : side;
 		HIPCHK(hipEventRecord(la->col_ready, U));
 		HIPCHK(hipStreamWaitEvent(chain, la->col_ready, 0));
