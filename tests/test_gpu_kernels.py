@@ -759,6 +759,30 @@ def test_rff_f32_bf16_split_kernel(L):
 	assert rc == -20 and b"workspace" in lib.stpy_last_error_string()
 
 
+def test_rff_f32_bf16_split_kernel_strided(L):
+	"""the same kernel with leading dimensions larger than the logical widths (x: d + 8, W: d + 4, out: m + 64): nothing is
+	written beyond column m, nothing is read beyond column d"""
+	lib = L.load()
+	n, d, m = 8192, 64, 1024
+	rng = np.random.RandomState(11)
+	xp = rng.uniform(-1, 1, size=(n, d + 8)).astype(np.float32)
+	Wp = (rng.normal(size=(m, d + 4)) / 3.0).astype(np.float32)
+	xp[:, d:] = 1e30          # poison: must never be read
+	Wp[:, d:] = 1e30
+	xd, Wd = dev(xp, torch.float32), dev(Wp, torch.float32)
+	wb = int(lib.stpy_rff_workspace_bytes(L.F32, n, d, m))
+	assert wb > 0
+	work = torch.empty(wb, dtype=torch.uint8, device="cuda:0")
+	out = torch.full((n, m + 64), 7.0, dtype=torch.float32, device="cuda:0")
+	scale = float(np.sqrt(2.0 / m))
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d + 8, d, L.ptr(Wd), d + 4, m, None, None, scale, L.ptr(out), m + 64, 0, L.ptr(work), wb, L.stream_ptr()), "rff")
+	got = out.cpu().numpy()
+	assert np.all(got[:, m:] == 7.0)
+	ref = O.rff_embed(xp[:256, :d].astype(np.float64), Wp[:, :d].astype(np.float64), m)
+	assert np.abs(got[:256, :m] - ref).max() < 2e-5 * scale
+	assert np.abs(got[:, :m]).max() <= scale * (1 + 1e-6)
+
+
 def test_rff_f32_streaming_kernel(L):
 	"""n >= 8192, m % 1024 == 0, d = 64: the persistent streaming kernel (stpy_tune key 9 = 1) against the tile kernel (2) and
 	the GEMM epilogue (0), plain and biased, with a row count that leaves the last stride of row blocks partly idle"""
