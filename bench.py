@@ -241,31 +241,167 @@ def extra_configs(dev, lib):
 def F_fp(n, m):
 	return flops_fit_predict(n, m)
 
+METRIC_FMT = "GP fit+mean_var wall-time (s), N=%d d=%d fp64"
+C4_ONE_GPU_SECONDS = 11.47      # BASELINE config 4's shape on ONE MI355X (tools/c4_single_gpu.py, end of round 2; re-measured by `--gpus 1` runs: extra_configs.C4.seconds)
+WORKLOADS = {"headline": (65536, 16, 4096), "c4": (131072, 32, 4096), "c2": (16384, 8, 4096)}
 
-def main():
+
+def _error_line(msg, n_gpus, n=65536, d=16, tb=None, **extra):
+	"""Every failure path ends in ONE JSON line with value null (not measured) and the reason."""
+	out = {"metric": METRIC_FMT % (n, d), "value": None, "unit": "s", "n_gpus": n_gpus, "higher_is_better": False, "scaling": "strong",
+		   "vs_baseline": None, "dtype": "f64", "data": "synthetic", "error": msg}
+	if tb:
+		out["traceback_tail"] = tb[-1500:]
+	out.update(extra)
+	return json.dumps(out)
+
+
+def parse_args(argv=None):
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--n", "--train-points", dest="n", type=int, default=65536)
-	ap.add_argument("--d", type=int, default=16)
-	ap.add_argument("--m", type=int, default=4096)
+	ap.add_argument("--config", choices=sorted(WORKLOADS), default="headline",
+					help="headline: N=65536 d=16 (BASELINE metric); c4: N=131072 d=32 (BASELINE config 4's shape); c2: N=16384 d=8")
+	ap.add_argument("--n", "--train-points", dest="n", type=int, default=0)
+	ap.add_argument("--d", type=int, default=0)
+	ap.add_argument("--m", type=int, default=0)
 	ap.add_argument("--nb", type=int, default=0)
+	ap.add_argument("--nb-dist", type=int, default=0, help="distribution block of the block-cyclic path (0: the class default for the size)")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-extra-configs", action="store_true")
-	args = ap.parse_args()
+	args = ap.parse_args(argv)
+	n0, d0, m0 = WORKLOADS[args.config]
+	args.n, args.d, args.m = args.n or n0, args.d or d0, args.m or m0
+	return args
 
+
+def self_launch(args, argv):
+	"""`python bench.py --gpus N` started plainly (WORLD_SIZE unset): start N fresh rank processes through torch.distributed.run,
+	relay rank 0's JSON line and exit with the children's return code.  This process has made NO GPU call (importing torch does
+	not initialise the runtime), and it never replaces itself: the ranks are children."""
+	import signal
+	import socket
+	import subprocess
+	import tempfile
+	with socket.socket() as sk:
+		sk.bind(("127.0.0.1", 0))
+		port = sk.getsockname()[1]
+	cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+		   "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+	env = dict(os.environ)
+	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL across processes)
+	env["STPY_BENCH_LAUNCHED_BY"] = "self"
+	limit = float(os.environ.get("STPY_BENCH_TIMEOUT_S", "1700"))
+	errf = tempfile.TemporaryFile(mode="w+")
+	proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=errf, env=env, text=True, start_new_session=True)
+	timed_out = False
+	try:
+		out, _ = proc.communicate(timeout=limit)
+	except subprocess.TimeoutExpired:
+		timed_out = True
+		try:
+			os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group started above
+		except ProcessLookupError:
+			pass
+		out, _ = proc.communicate()
+	errf.seek(0)
+	err = errf.read()
+	sys.stderr.write(err[-20000:])
+	line = None
+	for ln in (out or "").splitlines():
+		ln = ln.strip()
+		if ln.startswith("{") and '"metric"' in ln:
+			line = ln
+	rc = proc.returncode if not timed_out else 124
+	if line is None:
+		why = "timed out after %.0f s" % limit if timed_out else "rank processes ended with rc %s and printed no result line" % rc
+		line = _error_line("self-launch of %d ranks: %s" % (args.gpus, why), args.gpus, args.n, args.d, tb=err, launcher="bench.py self-launch (torch.distributed.run)")
+		rc = rc or 1
+	print(line, flush=True)
+	return rc
+
+
+def run_steps(gp, x, y, xt, warmup, steps, dist_path, lib=None):
+	"""`warmup` untimed steps, then exactly `steps` timed ones between barrier + synchronize; returns the elapsed seconds of this rank."""
+	def barrier():
+		if dist_path:
+			torch.distributed.barrier()
+		torch.cuda.synchronize()
+	out = None
+	for _ in range(warmup):
+		gp.fit_gp(x, y)
+		out = gp.mean_std(xt)
+	barrier()
+	if lib is not None:
+		lib.stpy_profile_enable(1)
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		gp.fit_gp(x, y)
+		out = gp.mean_std(xt)
+	barrier()
+	elapsed = time.perf_counter() - t0
+	if lib is not None:
+		lib.stpy_profile_enable(0)
+	return elapsed, out
+
+
+def max_over_ranks(elapsed, world, backend, dev):
+	if world > 1:
+		tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+		torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+		elapsed = float(tt.item())
+	return elapsed
+
+
+def traffic_from_profiles(lib_version, launches_per_step):
+	"""HBM traffic of the dominant kernel family: PMC counters cannot be collected inside this process, so the value comes from
+	the committed separate-pass rocprofv3 --pmc runs of this same command (profiles/*_pmc_traffic.json: FETCH_SIZE doubled per the
+	gfx950 correction + WRITE_SIZE), per launch -- and ONLY when that file was recorded with this very build of the library
+	(its `library_version`) and the same number of launches per step; otherwise null (stale numbers are not paired with this run)."""
+	import glob
+	info = {"traffic": None, "traffic_source": None}
+	cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+	if not cands:
+		info["traffic_note"] = "no profiles/*_pmc_traffic.json"
+		return info
+	src = cands[-1]
+	try:
+		with open(src) as fh:
+			rec = json.load(fh)
+	except Exception as exc:          # noqa: BLE001
+		info["traffic_note"] = "unreadable %s: %s" % (os.path.basename(src), exc)
+		return info
+	info["traffic_source"] = "profiles/" + os.path.basename(src)
+	info["traffic_source_gemm_launches_per_step"] = rec.get("gemm_launches")
+	info["traffic_source_library_version"] = rec.get("library_version")
+	if rec.get("library_version") != lib_version:
+		info["traffic_note"] = "null: the profile was recorded with library build %r, this run is %r (re-run tools/profile_round.sh)" % (rec.get("library_version"), lib_version)
+		return info
+	if rec.get("gemm_launches") and abs(rec["gemm_launches"] - launches_per_step) > 0.02 * launches_per_step:
+		info["traffic_note"] = "null: launches per step differ (profile %s, this run %.0f)" % (rec.get("gemm_launches"), launches_per_step)
+		return info
+	info["traffic"] = round(rec["per_launch_hbm_bytes"])
+	info["traffic_note"] = "HBM bytes per launch of this kernel family from separate rocprofv3 --pmc passes of this command with this build, 2*FETCH_SIZE + WRITE_SIZE"
+	return info
+
+
+def main(args):
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	if world != args.gpus:
-		if world == 1 and args.gpus > 1:
-			raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+		raise RuntimeError("--gpus %d but WORLD_SIZE=%d: start `python bench.py --gpus N` plainly (it launches its ranks itself) or through "
+						   "torch.distributed.run --nproc-per-node N" % (args.gpus, world))
 	# STPY_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box: the ranks share card 0 and the
 	# collectives are staged through the host (functional check of this script only, not a measurement)
 	backend = os.environ.get("STPY_BENCH_BACKEND", "nccl")
+	if not torch.cuda.is_available():
+		raise RuntimeError("no GPU visible to this process (the HIP path has no CPU fallback)")
 	if backend != "nccl":
 		local_rank = local_rank % max(torch.cuda.device_count(), 1)
+	elif world > torch.cuda.device_count():
+		raise RuntimeError("%d ranks on the nccl (RCCL) backend need %d GPUs, %d visible" % (world, world, torch.cuda.device_count()))
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
 	# STPY_BENCH_FORCE_DIST=1: take the block-cyclic code path (process group, sub-communicators, panel
@@ -286,42 +422,25 @@ def main():
 
 	from stpy_amd import GaussianProcess, _lib
 	lib = _lib.load()
+	lib_version = lib.stpy_version().decode()
 
 	n, d, m = args.n, args.d, args.m
-	gamma, s = math.sqrt(d), 0.1
-	x, y, xt = synth(n, d, m, dev)
+	s = 0.1
 
-	if dist_path:
-		from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
-		gp = DistributedGaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d, force_path=force_dist)
-	else:
-		gp = GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
-	gp.nb = args.nb
-
-	def step():
-		gp.fit_gp(x, y)
-		return gp.mean_std(xt)
-
-	def barrier():
+	def make_gp(dd, nn):
 		if dist_path:
-			torch.distributed.barrier()
-		torch.cuda.synchronize()
+			from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
+			kw = {"nb_dist": args.nb_dist} if args.nb_dist else {}
+			g = DistributedGaussianProcess(gamma=math.sqrt(dd), s=s, kappa=1.0, kernel_name="squared_exponential", d=dd, force_path=force_dist, **kw)
+		else:
+			g = GaussianProcess(gamma=math.sqrt(dd), s=s, kappa=1.0, kernel_name="squared_exponential", d=dd)
+		g.nb = args.nb
+		return g
 
-	for _ in range(args.warmup):
-		step()
-	barrier()
-	lib.stpy_profile_enable(1)
-	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		mu, std = step()
-	barrier()
-	elapsed = time.perf_counter() - t0
-	lib.stpy_profile_enable(0)
-	if world > 1:
-		tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-		torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-		elapsed = float(tt.item())
-	sec_per_step = elapsed / args.steps
+	x, y, xt = synth(n, d, m, dev)
+	gp = make_gp(d, n)
+	elapsed, (mu, std) = run_steps(gp, x, y, xt, args.warmup, args.steps, dist_path, lib)
+	sec_per_step = max_over_ranks(elapsed, world, backend, dev) / args.steps
 
 	# ---- live roofline of the dominant kernel from the event log (this rank)
 	def prof(tag):
@@ -340,18 +459,9 @@ def main():
 	_lib.check(lib.stpy_profile_read_union(0b10111 if dist_path else 0b0111, ctypes.byref(ub), ctypes.byref(uf), ctypes.byref(uc)), "stpy_profile_read_union")
 	achieved = uf.value / (ub.value * 1e-3) / 1e12 if ub.value > 0 else 0.0
 
-	# HBM traffic of the dominant kernel: PMC counters cannot be collected inside this process, so the
-	# value comes from the committed separate-pass rocprofv3 --pmc runs of this same command
-	# (profiles/*_pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), per launch.
-	traffic = None
-	try:
-		import glob
-		cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-		if cands and n == 65536 and d == 16 and m == 4096 and not dist_path:
-			with open(cands[-1]) as fh:
-				traffic = round(json.load(fh)["per_launch_hbm_bytes"])
-	except Exception:
-		traffic = None
+	tinfo = {"traffic": None, "traffic_source": None, "traffic_note": "null: only recorded for the single-GPU headline workload"}
+	if (n, d, m) == WORKLOADS["headline"] and not dist_path:
+		tinfo = traffic_from_profiles(lib_version, g_cnt / max(args.steps, 1))
 
 	# ---- multi-GPU: what moved and how busy every rank's MFMA GEMM was (gathered; one small host object per rank)
 	dist_info = None
@@ -362,49 +472,87 @@ def main():
 				"collectives_per_step": gp.stats["collectives"] // max(args.steps + args.warmup, 1)}
 		gathered = [None] * world
 		torch.distributed.all_gather_object(gathered, mine)
-		dist_info = {"rccl_ranks": world if backend == "nccl" else 0, "backend": backend, "grid": "%dx%d" % (gp.Pr, gp.Pc), "nb_dist": gp.NB, "per_rank": gathered}
+		dist_info = {"rccl_ranks": world if backend == "nccl" else 0, "backend": backend, "grid": "%dx%d" % (gp.Pr, gp.Pc), "nb_dist": gp.NB,
+					 "transport": getattr(gp, "transport", "collective"), "per_rank": gathered}
+	gp_nb = gp.NB if dist_path else None
+	result_check = {"mu_norm": float(torch.norm(mu)), "std_mean": float(std.mean()), "nan": bool(torch.isnan(std).any())}
+	del gp, mu, std, x, y, xt
+	torch.cuda.empty_cache()
+
+	# ---- BASELINE config 4's shape (N = 131 072, d = 32): the strong-scaling target of north_star.  One GPU: the reference time
+	# ---- of the curve; several: seconds, speed-up over one GPU and the fraction of the aggregate fp64 MFMA peak.
+	c4 = None
+	if args.config == "headline" and not args.no_extra_configs and (n, d, m) == WORKLOADS["headline"] and os.environ.get("STPY_BENCH_SKIP_C4", "0") != "1":
+		n4, d4, m4 = WORKLOADS["c4"]
+		try:
+			x4, y4, xt4 = synth(n4, d4, m4, dev)
+			g4 = make_gp(d4, n4)
+			e4, (mu4, sd4) = run_steps(g4, x4, y4, xt4, 1, 1 if world == 1 else 2, dist_path)
+			t4 = max_over_ranks(e4, world, backend, dev) / (1 if world == 1 else 2)
+			F4 = flops_fit_predict(n4, m4)
+			c4 = {"workload": "N=131072 d=32 SE fp64 fit_gp+mean_std, M=4096 (BASELINE config 4's shape)", "seconds": round(t4, 4), "n_gpus": world,
+				  "one_gpu_reference_seconds": C4_ONE_GPU_SECONDS if world > 1 else round(t4, 4),
+				  "speedup_vs_1gpu": round((C4_ONE_GPU_SECONDS if world > 1 else t4) / t4, 3),
+				  "bound": "mfma", "achieved": round(F4 / t4 / 1e12, 2), "peak": PEAK_FP64_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+				  "frac": round(F4 / t4 / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),
+				  "nb_dist": g4.NB if dist_path else None,
+				  "result_check": {"mu_norm": float(torch.norm(mu4)), "std_mean": float(sd4.mean()), "nan": bool(torch.isnan(sd4).any())}}
+			del g4, x4, y4, xt4, mu4, sd4
+		except Exception as exc:          # noqa: BLE001  (the headline line must survive a failure of the extra workload)
+			c4 = {"workload": "N=131072 d=32", "seconds": None, "error": "%s: %s" % (type(exc).__name__, exc)}
+			if dist_path:
+				raise
+		torch.cuda.empty_cache()
 
 	if rank == 0:
 		F = flops_fit_predict(n, m)
 		out = {
-			"metric": "GP fit+mean_var wall-time (s), N=%d d=%d fp64" % (n, d),
+			"metric": METRIC_FMT % (n, d),
 			"value": round(sec_per_step, 4), "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
 			"ms_per_step": round(sec_per_step * 1e3, 2), "higher_is_better": False,
 			"scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (REHEARSAL: %s backend, ranks share one GPU)" % backend,
 			"config": {"workload": "GaussianProcess.fit_gp + mean_std, SE kernel gamma=sqrt(d), s=0.1, N=%d train, M=%d test, d=%d, fp64" % (n, m, d),
-					   "n": n, "m": m, "d": d, "nb": args.nb or ("distribution block %d" % gp.NB if dist_path else "potrf panels 1024, recursive block solve (library defaults)"),
+					   "n": n, "m": m, "d": d, "nb": args.nb or ("distribution block %d" % gp_nb if dist_path else "potrf panels by size (library defaults), recursive block solve"),
 					   "parallelism": "2-D block-cyclic over %d GPU%s" % (world, "s" if world > 1 else " (forced: functional check of the distributed code path)") if dist_path else "single GPU"},
 			"step_tflops": round(F / sec_per_step / 1e12, 2),
 			"step_frac_of_fp64_mfma_peak": round(F / sec_per_step / 1e12 / (PEAK_FP64_MFMA_TFLOPS * world), 4),
-			"roofline": {"bound": "mfma", "kernel": "stpy::gemm_nt_dtv_kernel / gemm_nt_kernel<double>" if dist_path else "stpy::gemm_nt_dtv_kernel<SUB> (+ gemm_nt_kernel<double,...> for the ragged / fused-epilogue launches)", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
-						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": traffic,
-						 "traffic_note": "HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes of this command (profiles/), 2*FETCH_SIZE + WRITE_SIZE",
-						 "launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4), "busy_ms_per_step": round(ub.value / args.steps, 2),
-						 "algorithmic_gflop_per_launch": round(g_fl / max(g_cnt, 1) / 1e9, 3)},
+			"library": lib_version,
+			"roofline": dict({"bound": "mfma", "kernel": "stpy::gemm_nt_dtv_kernel / gemm_nt_kernel<double>" if dist_path else "stpy::gemm_nt_dtv_kernel<SUB> (+ gemm_nt_kernel<double,...> for the ragged / fused-epilogue launches)", "achieved": round(achieved, 2), "peak": PEAK_FP64_MFMA_TFLOPS,
+						 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4)}, **tinfo,
+						 **{"launches": int(g_cnt), "avg_launch_ms": round(g_ms / max(g_cnt, 1), 4), "busy_ms_per_step": round(ub.value / args.steps, 2),
+						 "algorithmic_gflop_per_launch": round(g_fl / max(g_cnt, 1) / 1e9, 3)}),
 			"breakdown_ms_per_step": {k: round(v[0] / args.steps, 2) for k, v in pr.items()},
-			"result_check": {"mu_norm": float(torch.norm(mu)), "std_mean": float(std.mean()), "nan": bool(torch.isnan(std).any())},
+			"result_check": result_check,
 		}
 		if dist_info is not None:
 			out["multi_gpu"] = dist_info
-		if world == 1 and not args.no_cpu_baseline:
-			del gp
-			torch.cuda.empty_cache()
-			if not args.no_extra_configs:
-				out["extra_configs"] = extra_configs(dev, lib)
-			out["cpu_baseline"] = cpu_baseline(d, lambda: GaussianProcess(gamma=gamma, s=s, kappa=1.0, kernel_name="squared_exponential", d=d), dev)
+		extra = {}
+		if c4 is not None:
+			extra["C4"] = c4
+		if world == 1 and not args.no_extra_configs and not dist_path:
+			extra.update(extra_configs(dev, lib))
+		if extra:
+			out["extra_configs"] = extra
+		if world == 1 and not args.no_cpu_baseline and not dist_path:
+			out["cpu_baseline"] = cpu_baseline(d, lambda: GaussianProcess(gamma=math.sqrt(d), s=s, kappa=1.0, kernel_name="squared_exponential", d=d), dev)
 		print(json.dumps(out), flush=True)
 	if dist_path:
 		torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
+	_args = parse_args()
+	if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		sys.exit(self_launch(_args, sys.argv[1:]))
 	try:
-		main()
-	except Exception as exc:                         # noqa: BLE001
-		# a multi-GPU run that dies must still say why on the one line the driver reads (value null = not measured)
-		if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+		main(_args)
+	except BaseException as exc:                         # noqa: BLE001
+		# a run that dies must still say why on the one line the driver reads (value null = not measured) -- any world size
+		if isinstance(exc, SystemExit) and exc.code in (0, None):
+			raise
+		if int(os.environ.get("RANK", "0")) == 0:
 			import traceback
-			print(json.dumps({"metric": "GP fit+mean_var wall-time (s), N=65536 d=16 fp64", "value": None, "unit": "s",
-							  "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "higher_is_better": False, "scaling": "strong",
-							  "error": "%s: %s" % (type(exc).__name__, exc), "traceback_tail": traceback.format_exc()[-1500:]}), flush=True)
-		raise
+			print(_error_line("%s: %s" % (type(exc).__name__, exc), int(os.environ.get("WORLD_SIZE", "1")), _args.n, _args.d, tb=traceback.format_exc()), flush=True)
+		if isinstance(exc, KeyboardInterrupt):
+			raise
+		sys.exit(1)

@@ -25,10 +25,14 @@
  *         stream must be issued by one thread at a time (they are ordered by the stream, like any HIP work); with them 64 bytes
  *         of device memory (the ticket / counter words of the one-launch vector solve), the library's only allocation;
  *       * the launch profiler's record table (stpy_profile_*), guarded by a mutex, off by default;
- *       * the stpy_tune A/B switches: process-wide integers read at launch time.  They exist for tools/ timing
- *         experiments, are never written by the shipped host code, and must not be changed while another
- *         thread is inside the library.  Behaviour a caller may legitimately want per call is a `flags`
- *         argument instead (STPY_FLAG_*);
+ *       * the five ROUTE switches of stpy_tune (which shipped kernel serves a call where the library normally decides by
+ *         size): process-wide integers read at launch time, never written by the shipped host code -- tests/ use them to
+ *         reach every shipped path at small sizes; they must not be changed while another thread is inside the library.
+ *         Behaviour a caller may legitimately want per call is a `flags` argument instead (STPY_FLAG_*).  The timing
+ *         experiments of tools/ (ablation bits, measured-and-dropped kernel variants, reserved-CU streams, in-kernel
+ *         stamps) are NOT in this library: they live in the lab build (make EXPERIMENTS=1 -> libstpy_hip_lab.so);
+ *       * one sticky device error word per caller stream (part of the 64 bytes above), read by stpy_async_status;
+ *   - exported symbols: exactly the functions declared in this header (the build hides everything else);
  *   - return value: 0 = ok, <0 = invalid argument (-(index of the argument), 1-based) or
  *     -1000-hipError for a failed launch; numerical failure of the factorisation is reported
  *     through the device word `info_dev` (0 = ok, j>0 = leading minor j not positive definite),
@@ -44,6 +48,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 enum { STPY_F64 = 0, STPY_F32 = 1 };
 
@@ -236,21 +241,20 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d,
  * (ms), the summed algorithmic flops and the number of launches of that tag.
  */
 void stpy_profile_enable(int enable);
-/* A/B switches used by tools/ (process-wide; see "state kept by the library" at the top -- the shipped host code never
- * writes them):
- * 0 first-round workgroup stagger of the GEMM (40000 cycles; 0 off; 1 half a tile) · 1 phase-ablation bits for timing experiments (0) ·
- * 2 scalar diagonal-block kernel (0) · 3 / 4 pass depth and workgroup target of the left-looking block solve ·
- * 5 block-solve algorithm (0 auto, 1 right-looking, 2 left-looking) · 6 direct-to-VGPR GEMM from this many tiles (1; 0 never) ·
- * 7 diagonal block first below this order (8192) · 8 one-volley K = 128 kernel up to this many 64-tiles (768; 0 never) ·
- * 9 fp32 RFF route (1: streaming kernel for large d = 64 shapes + tile kernel; 2: tile kernel only; 0: GEMM epilogue) ·
- * 10 look-ahead panels run in "beside" mode (kernels that fit into what two update workgroups leave over on a CU) while the
- *    trailing update has at least this many rows (0: always) · 11 the four-wave / 64-VGPR diagonal-block kernel in that mode (0) ·
- * 12 / 13 potrf updates trailing matrices of at most / at least this many rows on a stream masked off one CU per XCD and runs
- *    the diagonal-block kernel on those reserved CUs (0 = never / 2048) · 14 / 15 adaptive panel width of potrf: 256 columns while
- *    at most this many rows are left, 512 up to the second value, 1024 beyond (2048 / 16384) ·
- * 16 the vector solves as one dataflow launch for n a multiple of 128 (1; 0: the chain of per-block launches) ·
- * 17 leaf width of the recursive block solve that runs as one strip launch (1 = 1024 up to 8192 rows, 512 above; 512; 1024; 0 = off) ·
- * 18 Cholesky panels: the rows below the panel's diagonal block as one strip launch (0 = off, the default; 2 = only when nothing else runs, i.e. the first panel; 1 = always) */
+/* Errors only the device can detect after a call has returned: waits for `stream`, returns 0, or 1 when a hand-off wait of the
+ * one-launch vector solve (stpy_trsv) gave up -- that solve's output is then NaN from the affected block on, so every quantity
+ * derived from it is NaN as well -- and clears the word; < 0: the query itself failed. */
+int stpy_async_status(void* stream);
+/* Route switches (process-wide; see "state kept by the library" at the top -- the shipped host code never writes them).
+ * Unknown keys are ignored; stpy_tune_get returns -1 for them.
+ *   5  block-solve algorithm: 0 auto (recursive halving with strip leaves), 1 right-looking sweep, 2 left-looking with K passes,
+ *      3.. recursive with leaves of 128 << (value - 3) columns
+ *   8  K = 128 products with at most this many 64 x 64 tiles take the one-volley kernel (768; 0 never)
+ *   9  fp32 RFF route: 1 streaming kernel for large d = 64 shapes (bf16-split form when a workspace is passed) + tile kernel for the
+ *      other d = 32 / 64 shapes; 5 the same but always the fp32-MFMA streaming kernel; 2 tile kernel only; 0 GEMM epilogue only
+ *   16 vector solves as one dataflow launch for n a multiple of 128 (1; 0: the chain of per-block launches)
+ *   17 leaf width of the recursive block solve that runs as one strip launch (1 = 1024 up to 8192 rows, 512 above; 512; 1024; 0 = off)
+ * The lab build (libstpy_hip_lab.so) adds the experiment knobs listed in csrc/common.h (STPY_KNOB_LIST). */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */
 int stpy_tune_get(int key);
@@ -258,6 +262,7 @@ int stpy_profile_read(int tag, double* total_ms, double* total_flops, int64_t* l
 /* union of the launch intervals of all tags in tagmask (bit t = tag t): overlapping launches counted once */
 int stpy_profile_read_union(int tagmask, double* busy_ms, double* total_flops, int64_t* launches);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstpy_hip.so")
+# STPY_HIP_LIB=lab selects the lab build (make -C stpy_amd/csrc EXPERIMENTS=1: the product kernels plus the experiment knobs and the
+# measured-and-dropped variants tools/ compares against); unset = the product library.  Same C ABI either way.
+LIB_PATH = os.path.join(_HERE, "libstpy_hip_lab.so" if os.environ.get("STPY_HIP_LIB", "") == "lab" else "libstpy_hip.so")
 
 F64, F32 = 0, 1
 K_SE, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR, K_POLY = 0, 1, 2, 3, 4, 5
@@ -50,6 +52,7 @@ SIGNATURES = {
 	"stpy_rff_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
 	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _dbl, _vp, _i64, _i32, _vp, _i64, _vp]),
 	"stpy_profile_enable": (None, [_i32]),
+	"stpy_async_status": (_i32, [_vp]),
 	"stpy_profile_read_union": (_i32, [_i32, _c.POINTER(_dbl), _c.POINTER(_dbl), _c.POINTER(_i64)]),
 	"stpy_tune": (None, [_i32, _i32]),
 	"stpy_tune_get": (_i32, [_i32]),

@@ -84,7 +84,16 @@ using namespace stpy;
 
 extern "C" {
 
-const char* stpy_version(void) { return "stpy_hip 0.1 (gfx950)"; }
+#ifndef STPY_SRC_HASH
+#define STPY_SRC_HASH "unhashed"
+#endif
+// "stpy_hip <version> (gfx950) src <hash of the sources this build was compiled from>[ lab]": bench.py pairs a committed PMC profile
+// with a run only when the two strings agree
+const char* stpy_version(void) { return "stpy_hip 0.3 (gfx950) src " STPY_SRC_HASH
+#if STPY_LAB
+	" lab"
+#endif
+	; }
 const char* stpy_last_error_string(void) { return g_err; }
 
 // a workspace that is too small is refused here: the kernels cannot check it and would write past its end
@@ -343,63 +352,66 @@ int stpy_rff_embed(int dtype, const void* x, int64_t n, int64_t ldx, int d, cons
 	         rff_embed<float>((const float*)x, n, ldx, d, (const float*)W, ldw, m, (const float*)bias, (const float*)feat_scale, scale, (float*)out, ldo, transposed, work, work_bytes, st));
 }
 
-/* experiment knobs (benchmarks only): key 0 = gemm first-round stagger on/off */
+/* Route switches (every build; include/stpy_hip.h lists them) and, in the lab build only, the experiment knobs of common.h. */
+#if STPY_LAB
+}  // extern "C"
+namespace stpy {
+#define STPY_KNOB_DEFINE(key, name, dflt) int name = dflt;
+STPY_KNOB_LIST(STPY_KNOB_DEFINE)
+#undef STPY_KNOB_DEFINE
+}
+extern "C" {
+#endif
+
 void stpy_tune(int key, int value)
 {
-	if (key == 0) g_gemm_stagger = value;
-	if (key == 1) g_gemm_exp = value;
-	if (key == 2) g_potf2_scalar = value;
-	if (key == 3) g_trsm_pass_depth = value > 0 ? value : 1024;
-	if (key == 4) g_trsm_wg_target = value > 0 ? value : 2048;
-	if (key == 5) g_trsm_right_looking = value;
-	if (key == 6) g_gemm_dtv = value;
-	if (key == 7) g_potrf_diag_first_below = value;
-	if (key == 8) g_gemm_k128 = value;
-	if (key == 9) g_rff_tile = value;
-	if (key == 10) g_potrf_beside_min = value;
-	if (key == 11) g_potf2_sliver = value;
-	if (key == 12) g_potrf_reserve_below = value;
-	if (key == 13) g_potrf_reserve_above = value;
-	if (key == 14) g_potrf_nb256_upto = value;
-	if (key == 15) g_potrf_nb512_upto = value;
-	if (key == 16) g_trsv_flow = value;
-	if (key == 18) g_potrf_strip = value;
-	if (key == 19) g_rff_wgs = value;
-	if (key == 20) g_gemm_tri_diag_last = value;
-	if (key == 21) g_potrf_serial_below = value;
-	if (key == 17) g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0;
+	switch (key) {
+	case 5: g_trsm_right_looking = value; return;
+	case 8: g_gemm_k128 = value; return;
+	case 9: if (STPY_LAB || value != 3) g_rff_tile = value; return;          // (3 = the direct-store streaming variant: lab build only)
+	case 16: g_trsv_flow = value; return;
+	case 17: g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0; return;
+	default: break;
+	}
+#if STPY_LAB
+	if (key == 3) { g_trsm_pass_depth = value > 0 ? value : 1024; return; }
+	if (key == 4) { g_trsm_wg_target = value > 0 ? value : 2048; return; }
+#define STPY_KNOB_SET(k, name, dflt) if (key == k) { name = value; return; }
+	STPY_KNOB_LIST(STPY_KNOB_SET)
+#undef STPY_KNOB_SET
+#endif
 }
 
-/* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
+/* current value of a switch; -1: no such key in this build */
 int stpy_tune_get(int key)
 {
 	switch (key) {
-	case 0: return g_gemm_stagger;
-	case 1: return g_gemm_exp;
-	case 2: return g_potf2_scalar;
-	case 3: return g_trsm_pass_depth;
-	case 4: return g_trsm_wg_target;
 	case 5: return g_trsm_right_looking;
-	case 6: return g_gemm_dtv;
-	case 7: return g_potrf_diag_first_below;
 	case 8: return g_gemm_k128;
 	case 9: return g_rff_tile;
-	case 10: return g_potrf_beside_min;
-	case 11: return g_potf2_sliver;
-	case 12: return g_potrf_reserve_below;
-	case 13: return g_potrf_reserve_above;
-	case 14: return g_potrf_nb256_upto;
-	case 15: return g_potrf_nb512_upto;
 	case 16: return g_trsv_flow;
 	case 17: return g_trsm_strip;
-	case 18: return g_potrf_strip;
-	case 19: return g_rff_wgs;
-	case 20: return g_gemm_tri_diag_last;
-	case 21: return g_potrf_serial_below;
-	default: return -1;
+	default: break;
 	}
+#if STPY_LAB
+#define STPY_KNOB_GET(k, name, dflt) if (key == k) return name;
+	STPY_KNOB_LIST(STPY_KNOB_GET)
+#undef STPY_KNOB_GET
+#endif
+	return -1;
 }
 
+/* Errors that only the device can detect after the call has returned (today: a hand-off wait of the one-launch vector solve that
+ * gave up -- its output is then NaN).  Waits for `stream`, returns 0 or a positive code (1 = stpy_trsv hand-off timed out) and
+ * clears the word; < 0: the query itself failed. */
+int stpy_async_status(void* stream)
+{
+	int status = 0;
+	const int rc = trsv_async_status((hipStream_t)stream, &status);
+	return rc ? rc : status;
+}
+
+/* profiler: enable != 0 starts a fresh recording; read() waits for the recorded events */
 void stpy_profile_enable(int enable)
 {
 	std::lock_guard<std::mutex> lock(g_prof_mutex);

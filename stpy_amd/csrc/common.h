@@ -10,16 +10,32 @@ namespace stpy {
 
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
+// ---- switches ---------------------------------------------------------------------------------------------------------
+// ROUTE switches (stpy_tune keys 5, 8, 9, 16, 17; every build): which of the SHIPPED kernels serves a call where the library
+// normally decides by size -- tests/ use them to reach every shipped path at small sizes.  Process-wide, read at launch time.
+extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip;
+// EXPERIMENT knobs: compile-time constants in the product library (the measured defaults); variables behind stpy_tune only in
+// the lab build (make EXPERIMENTS=1 -> libstpy_hip_lab.so, used by tools/).  The kernels and code paths that only a non-default
+// value reaches are compiled under #if STPY_LAB, so the product library does not carry them.  Where each default comes from is
+// documented at the place that reads it (gemm.hip, potrf.hip, solve.hip, rff.hip).
+#ifdef STPY_EXPERIMENTS
+#define STPY_LAB 1
+#define STPY_KNOB(key, name, dflt) extern int name;
+#else
+#define STPY_LAB 0
+#define STPY_KNOB(key, name, dflt) constexpr int name = dflt;
+#endif
+#define STPY_KNOB_LIST(X) \
+	X(0, g_gemm_stagger, 40000) X(1, g_gemm_exp, 0) X(2, g_potf2_scalar, 0) X(3, g_trsm_pass_depth, 1024) X(4, g_trsm_wg_target, 2048) \
+	X(6, g_gemm_dtv, 1) X(7, g_potrf_diag_first_below, 8192) X(10, g_potrf_beside_min, 0) X(11, g_potf2_sliver, 0) \
+	X(12, g_potrf_reserve_below, 0) X(13, g_potrf_reserve_above, 2048) X(14, g_potrf_nb256_upto, 2048) X(15, g_potrf_nb512_upto, 16384) \
+	X(18, g_potrf_strip, 0) X(19, g_rff_wgs, 0) X(20, g_gemm_tri_diag_last, 0) X(21, g_potrf_serial_below, 0) X(22, g_trsv_fault_ticket, -1)
+STPY_KNOB_LIST(STPY_KNOB)
+constexpr int g_gemm_dtv_min_k = 64;
 // panel width when the caller passes nb = 0: narrower panels shorten the latency-bound panel chain, which a
-// small trailing matrix cannot hide; the thresholds are set (and documented with their measurements) in potrf.hip
-extern int g_potrf_nb256_upto, g_potrf_nb512_upto;          // stpy_tune keys 14 / 15
+// small trailing matrix cannot hide; the thresholds are documented with their measurements in potrf.hip
 inline int potrf_auto_nb(int64_t n) { return n <= g_potrf_nb256_upto ? 256 : (n <= g_potrf_nb512_upto ? 512 : POTRF_DEFAULT_NB); }
 
-extern int g_gemm_stagger;
-extern int g_gemm_exp;
-extern int g_gemm_dtv, g_gemm_dtv_min_k, g_gemm_k128;
-extern int g_rff_tile;
-extern int g_potf2_scalar, g_potf2_sliver;
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
@@ -100,7 +116,6 @@ template <typename T>
 int trsm_right_lt(int64_t m, int64_t n, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, int nb, hipStream_t st, bool upper_rhs = false, T* work = nullptr, int gflags = 0);
 int trsm_auto_nb(int64_t m);
 constexpr int TRSM_MAX_PASSES = 16;      // split-K of the long left-looking products (needs the workspace)
-extern int g_trsm_pass_depth, g_trsm_wg_target, g_trsm_right_looking, g_trsv_flow, g_trsm_strip;
 // which form stpy_trsm_right_lt takes (shared by the solve and by stpy_trsm_workspace_bytes): the recursive one needs no workspace
 inline bool trsm_is_recursive(size_t elem, int64_t m, bool upper_rhs)
 {
@@ -112,8 +127,6 @@ inline bool trsm_is_recursive(size_t elem, int64_t m, bool upper_rhs)
 template <typename T>
 int trsm_strip(int64_t m, const T* Ld, int64_t ldl, const T* W, T* X, int64_t ldx, T* X2, int64_t ldx2, int64_t w, hipStream_t st);
 bool trsm_strip_ok(size_t elem, const void* L, int64_t ldl, const void* winv);
-extern int g_potrf_strip, g_rff_wgs, g_gemm_tri_diag_last, g_potrf_serial_below;
-extern int g_potrf_diag_first_below, g_potrf_beside_min, g_potrf_reserve_below, g_potrf_reserve_above;
 template <typename T>
 int potri_lower(int64_t n, const T* L, int64_t ldl, const T* winv, T* Kinv, int64_t ldk, T* work, hipStream_t st);
 template <typename T>
@@ -125,6 +138,7 @@ template <typename T>
 int predict_finish(int64_t m, T* mu, const T* sumsq, const T* kdiag, double scale, T* sigma, int clamp, hipStream_t st);
 template <typename T>
 int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int trans, hipStream_t st);
+int trsv_async_status(hipStream_t st, int* status);      // solve.hip: sticky device error word of the one-launch vector solves on `st`
 template <typename T>
 int predict(int64_t m, int64_t n, const T* X, int64_t ldx, const T* z, const T* kdiag, T* mu, T* sigma, int clamp, hipStream_t st);
 template <typename T>

@@ -33,13 +33,18 @@ constexpr int BM = 128, BN = 128, NTHREADS = 256;
 // K tile: one 128-byte row per operand row (16 doubles / 32 floats), so both types share the LDS byte layout,
 // the LDS-DMA pieces and the swizzle
 template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof(T); };
-int g_gemm_stagger = 40000;    // first-round offset (cycles) between the two workgroups of a CU in launches of >= 4096 tiles (stpy_tune key 0; 0 = off, 1 = half a tile)
-int g_gemm_tri_diag_last = 0;  // stpy_tune key 20: lower-triangular launches enumerate their diagonal super-tiles last (0 = row-major triangle, the default:
+// g_gemm_stagger = 40000:     first-round offset (cycles) between the two workgroups of a CU in launches of >= 4096 tiles (stpy_tune key 0; 0 = off, 1 = half a tile)
+// g_gemm_tri_diag_last = 0:   stpy_tune key 20: lower-triangular launches enumerate their diagonal super-tiles last (0 = row-major triangle, the default:
                                // tools/potrf_sweep.py "20=0|1" shows no difference at any size -- 1370.07 vs 1370.03 ms at N = 65 536)
-int g_gemm_dtv = 1;            // A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
-int g_gemm_dtv_min_k = 64;
+// g_gemm_dtv = 1:             A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
+// g_gemm_dtv_min_k = 64
 int g_gemm_k128 = 768;           // K = 128 products with at most this many 64 x 64 tiles take the one-volley kernel (stpy_tune key 8; 0 = never)
-int g_gemm_exp = 0;        // timing experiments only (results are wrong when != 0)
+// g_gemm_exp = 0:             timing experiments only, lab build (results are wrong when != 0)
+#if STPY_LAB
+#define STPY_EXP(p) ((p).exp)
+#else
+#define STPY_EXP(p) 0
+#endif
 constexpr int ST = 8;   // super-tile edge in tiles (64 tiles = the 64 workgroups one XCD holds at 2 per CU)
 
 constexpr int BC_MAX_ROWS = 64;
@@ -80,10 +85,14 @@ struct GemmArgs {
 	// split-K (few output tiles, long K): the super-tile range is enumerated ksplit times; pass s
 	// contracts K range [s*kchunk, (s+1)*kchunk) into the partial result at C + s*split_stride
 	int ksplit, kchunk; int64_t split_stride;
+#ifdef STPY_STAMPS
 	unsigned long long* dbg;      // diagnostic builds (-DSTPY_STAMPS) only: in-kernel time stamps, never read by any kernel
+#endif
 };
+#ifdef STPY_STAMPS
 unsigned long long* g_gemm_dbg = nullptr;
 extern "C" void stpy_debug_set_stamp_buffer(void* p) { g_gemm_dbg = (unsigned long long*)p; }
+#endif
 
 // Random-Fourier-feature epilogue: scale * cos(q + b) or scale * sin(q).  fp64: libm-accurate.
 // fp32: the phase is reduced to revolutions in fp32 (q/2pi minus its nearest integer, exact for
@@ -395,7 +404,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);     // read-side swizzle of this lane's rows (row & 15 == r16)
 	int buf = 0;
 	for (int kt = 0; kt < KT; ++kt) {
-		if (kt + 1 < KT && !(p.exp & 1)) {
+		if (kt + 1 < KT && !(STPY_EXP(p) & 1)) {
 			if (DMA) dma_issue(buf ^ 1, kbeg + (kt + 1) * BK);
 			else gload(kbeg + (kt + 1) * BK);
 		}
@@ -421,10 +430,10 @@ void gemm_nt_kernel(GemmArgs<T> p)
 					for (int tn = 0; tn < 4; ++tn)
 						acc[tm][tn] = MM::mma(fa[tm][s], fb[tn][s], acc[tm][tn]);
 		}
-		if (!DMA && kt + 1 < KT && !(p.exp & 2)) lstore(buf ^ 1);
+		if (!DMA && kt + 1 < KT && !(STPY_EXP(p) & 2)) lstore(buf ^ 1);
 		if (DMA) dma_wait();       // this wave's pieces of the next tile have landed; the barrier publishes them
-		if (!(p.exp & 4)) __syncthreads();
-		if (!(p.exp & 8)) buf ^= 1;
+		if (!(STPY_EXP(p) & 4)) __syncthreads();
+		if (!(STPY_EXP(p) & 8)) buf ^= 1;
 	}
 
 	// ---- fused random-Fourier-feature epilogue: ONE uniform branch around the whole transform (a
@@ -487,7 +496,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 		const int prow = lane / LPR, pcol = (lane % LPR) * CHW;
 		const bool algebra = p.g_combine != STPY_OUT_SET, add = p.g_combine == STPY_OUT_ADD;
 		const bool on_diag = p.g_diag != T(0) && row0 == col0;          // tiles are 128-aligned: only diagonal tiles hold i == j
-		const bool no_store = (p.exp & 16) != 0;                        // timing ablation (stpy_tune key 1 = 16): the fill without its stores
+		const bool no_store = (STPY_EXP(p) & 16) != 0;                        // timing ablation (stpy_tune key 1 = 16): the fill without its stores
 		auto finish_slab = [&](auto TM) __attribute__((always_inline)) {
 			constexpr int tm = decltype(TM)::value;          // (a compile-time index: a run-time one would put the accumulators into scratch)
 			if (algebra) {         // kernel algebra: out (+|*)= k, the old slab read 16 values at a time
@@ -1264,7 +1273,9 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		p.kskip = 1;
 	}
 	p.ksplit = 1; p.kchunk = 0; p.split_stride = 0;
+#ifdef STPY_STAMPS
 	p.dbg = g_gemm_dbg;
+#endif
 	if (ksplit > 1) {       // partial products go to the packed workspace [ksplit][m][n]; summed below
 		p.ksplit = ksplit;
 		p.kchunk = (int)kchunk;

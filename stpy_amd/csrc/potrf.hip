@@ -22,7 +22,7 @@ namespace stpy {
 
 // default outer panel width: 1024 halves the read+write passes over the trailing matrix compared
 // with 512 (measured 2 % faster end to end at N = 65 536); the solves keep 512 (see solve.hip)
-int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B runs)
+// g_potf2_scalar = 0 (lab knob, key 2): 1 = the column-by-column VALU kernel (kept for A/B runs in the lab build)
 // stpy_tune key 18: the rows below a panel's diagonal block as one strip launch (solve.hip) instead of two products per 128 columns.
 // 0 (default): off.  1: every panel, on the look-ahead stream -- the strip kernel's 120-202 VGPRs wait for update workgroups to retire.
 // 2: only the first panel (nothing else on the chip: no measurable difference).  3: the look-ahead stream factors only the panel's
@@ -31,17 +31,18 @@ int g_potf2_scalar = 0;    // 1: the column-by-column VALU kernel (kept for A/B 
 // against 35.5 / 193 / 1381 (1), 35.8 / 197.5 / 1403 (3), 37.8 / 203 / 1407 (3 + reserved)): in the kernel trace the diagonal-block
 // kernel alone is 21 of the 35 ms at N = 16 384 (165 us average beside the update, 58 us alone) whatever surrounds it, and keeping
 // the update off eight CUs costs more than that kernel gains.
-int g_potrf_strip = 0;
-int g_potrf_serial_below = 0;          // stpy_tune key 21 (see potrf()): no look-ahead below this many remaining rows.  Off: the fully serial
+// g_potrf_strip = 0 (lab knob, key 18)
+// g_potrf_serial_below = 0:            stpy_tune key 21 (see potrf()): no look-ahead below this many remaining rows.  Off: the fully serial
                                        // order costs 42.4 ms at N = 16 384 against 35.2 overlapped (the chain ALONE is ~170 us per 128-block at that height)
 // stpy_tune key 11 (0 = off, the default): blocks factored beside a trailing update take the 64-VGPR / four-wave form below.
 // Measured (tools/potrf_sweep.py, gpurun_out/potrf_sweep3.log): it is placed at once, as intended, but then RUNS 8x slower
 // beside the real update than alone (730-770 us against 94 us in the kernel trace) and loses to the eight-wave kernel that
 // waits for a slot (N = 16 384 potrf 41.0 ms against 36.7 ms).  Kept switchable for the next experiment, not used.
-int g_potf2_sliver = 0;
+// g_potf2_sliver = 0 (lab knob, key 11)
 constexpr int PT_THREADS = 512;
 constexpr int SLD = 132;     // LDS row stride in elements: 132 = 4 (mod 32) keeps the (row, k mod 4) lane map conflict-free
 
+#if STPY_LAB
 // One workgroup: Cholesky of a (<=128)x(<=128) SPD block + inverse of its factor.
 //   A    : block in global memory (lower triangle read; L written back to the lower triangle)
 //   W    : 128x128 row-major, receives inverse(L) (zeros above the diagonal, identity padding)
@@ -157,6 +158,8 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 		W[idx] = (c <= i) ? S[c * SLD + i] : T(0);
 	}
 }
+
+#endif  // STPY_LAB (scalar diagonal-block kernel)
 
 // ------------------------------------------------------------------------------------------
 // MFMA-blocked version of the same job (the default): the 128x128 block is processed in 16-wide
@@ -447,6 +450,7 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 #endif
 }
 
+#if STPY_LAB
 // ------------------------------------------------------------------------------------------
 // "Sliver" form of the same kernel for blocks factored WHILE a trailing update floods the chip (look-ahead panels):
 // 256 threads capped at 64 VGPRs and the same 83 KiB of LDS, i.e. it fits into what two update workgroups leave over on
@@ -648,27 +652,36 @@ void potf2_trtri_sliver_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	}
 }
 
+#endif  // STPY_LAB (four-wave diagonal-block kernel)
+
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st, bool beside)
 {
-	const size_t lds_old = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
 	const size_t lds_new = (size_t)(TRI + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
-	const size_t lds_sliver = (size_t)(TRI + NSB * SB * WLD + PS_WAVES * SB * WLD) * sizeof(T);
 	static std::atomic<bool> attr_set[2];          // (idempotent: two threads racing here both set the same attribute values)
 	const int which = sizeof(T) == 8 ? 0 : 1;
+#if STPY_LAB
+	const size_t lds_old = (size_t)(IB * SLD + 2 * IB) * sizeof(T);
+	const size_t lds_sliver = (size_t)(TRI + NSB * SB * WLD + PS_WAVES * SB * WLD) * sizeof(T);
+#endif
 	if (!attr_set[which].load(std::memory_order_acquire)) {
-		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
-		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
+		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
+#if STPY_LAB
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_sliver_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliver);
+#endif
 		if (e != hipSuccess) { set_error("potf2: hipFuncSetAttribute(%zu B LDS) failed: %s", lds_new, hipGetErrorString(e)); return -1000 - (int)e; }
 		attr_set[which].store(true, std::memory_order_release);
 	}
+#if STPY_LAB
 	if (g_potf2_scalar)
 		hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(PT_THREADS), lds_old, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	else if (beside && g_potf2_sliver)
 		hipLaunchKernelGGL((potf2_trtri_sliver_kernel<T>), dim3(1), dim3(PS_THREADS), lds_sliver, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	else
-		hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+#endif
+	hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	(void)beside;
 	return check_launch("potf2_trtri");
 }
 
@@ -677,25 +690,25 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 // the small panel kernels are dispatched ahead of the queued trailing-update workgroups as CU slots free up.
 // Two host threads on two streams get two sets; calls on one stream are enqueued in program order and the events
 // of a set are only ever recorded / awaited by calls on that stream, so re-use across calls needs no further care.
-int g_potrf_diag_first_below = 8192;     // stpy_tune key 7
+// g_potrf_diag_first_below = 8192:     stpy_tune key 7
 // stpy_tune key 10: a look-ahead panel whose trailing update still has at least this many rows runs BESIDE that update and
 // takes the "sliver" GEMM for its panel products (gemm.hip: fits into what two update workgroups leave over on a CU, so it
 // is placed at once) instead of the tile kernels, which wait for an update workgroup to exit, or the 128 KiB one-volley
 // kernel, which needs a CU without any update workgroup.  tools/potrf_sweep.py, one process: with the threshold at 0 (every
 // look-ahead panel) potrf takes 10.2 / 36.7 / 194.4 / 1396 ms at N = 8192 / 16 384 / 32 768 / 65 536 against
 // 11.6 / 40.4 / 206.5 / 1411 ms without the beside mode.
-int g_potrf_beside_min = 0;
+// g_potrf_beside_min = 0 (lab knob, key 10)
 // stpy_tune keys 12 / 13: trailing matrices with at most / at least this many rows are updated in reserved mode (see potrf());
 // 12 = 0 (the default) switches the mode off.  Measured, one process (tools/potrf_sweep.py, gpurun_out/potrf_sweep6.log): with the
 // mode on for every trailing matrix <= 24 576 rows potrf takes 10.5 / 38.7 / 208.0 / 1385 ms at N = 8192 / 16 384 / 32 768 /
 // 65 536 against 10.1 / 36.5 / 195.9 / 1371 ms without: the diagonal-block kernel does run at its stand-alone speed on its
 // reserved CU, but the update loses more (3 % of the CUs, 62 instead of 64 slots per XCD under a 64-tile super-tile map, and two
 // event hand-overs per 128-column block) than the chain gains.  Kept switchable; not used.
-int g_potrf_reserve_below = 0, g_potrf_reserve_above = 2048;
+// g_potrf_reserve_below = 0, g_potrf_reserve_above = 2048 (lab knobs, keys 12 / 13)
 // stpy_tune keys 14 / 15.  With the panel products in "beside" mode the chain of a wide panel is cheaper than it was, and wide
 // panels win (tools/potrf_sweep.py, gpurun_out/potrf_sweep8.log / 10.log, one process: N = 16 384 36.5 -> 34.4 ms, 32 768 196 -> 190 ms
 // against the former 16384 / 32768 thresholds; N = 65 536 unchanged within 0.2 %)
-int g_potrf_nb256_upto = 2048, g_potrf_nb512_upto = 16384;
+// g_potrf_nb256_upto = 2048, g_potrf_nb512_upto = 16384 (lab knobs, keys 14 / 15)
 namespace {
 struct LaKey { int device; hipStream_t stream; bool operator<(const LaKey& o) const { return device != o.device ? device < o.device : stream < o.stream; } };
 std::mutex g_la_mutex;
@@ -721,13 +734,14 @@ int lookahead_acquire(hipStream_t caller, LookAhead** out)
 		delete la;
 		return -1002;
 	}
-	if (hipMalloc(&la->trsv_sync, 64) != hipSuccess) { (void)hipGetLastError(); la->trsv_sync = nullptr; }          // (the vector solves then take the step kernels)
+	if (hipMalloc(&la->trsv_sync, 64) != hipSuccess || hipMemset(la->trsv_sync, 0, 64) != hipSuccess) { (void)hipGetLastError(); la->trsv_sync = nullptr; }          // (the vector solves then take the step kernels)
 	g_la_map[key] = la;
 	*out = la;
 	return 0;
 }
 
 
+#if STPY_LAB
 // Created on first use only (the mode is off by default, stpy_tune key 12): masked streams alive at process exit have been
 // seen to crash the profiler's finalisation.
 static std::vector<LookAhead*> g_la_masked;          // objects that own CU-masked streams (guarded by g_la_mutex)
@@ -765,6 +779,10 @@ static void lookahead_reserved_streams(LookAhead* la)
 		} else g_la_masked.push_back(la);
 	}
 }
+
+#else
+static void lookahead_reserved_streams(LookAhead*) {}          // (reserved-CU mode: lab build only; g_potrf_reserve_below is the constant 0 here)
+#endif
 
 template <typename T>
 static bool potrf_panel_can_strip(int64_t n, int64_t k, int64_t kb, const T* A, int64_t lda, const T* winv, int64_t ldp)

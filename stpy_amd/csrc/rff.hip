@@ -17,7 +17,7 @@
 
 namespace stpy {
 
-int g_rff_wgs = 0;              // stpy_tune key 19: workgroups of the streaming kernel (0 = 512, two per CU)
+// g_rff_wgs = 0 (lab knob):    stpy_tune key 19: workgroups of the streaming kernel (0 = 512, two per CU)
 int g_rff_tile = 1;             // dedicated fp32 kernels (stpy_tune key 9): 1 = streaming kernel for large d = 64 shapes, tile kernel for
                                 // the other d = 32 / 64 shapes; 2 = tile kernel only; 0 = always the GEMM epilogue
 
@@ -69,6 +69,9 @@ void rff_tile_f32_kernel(const float* __restrict__ x, int64_t ldx, const float* 
                          float* __restrict__ out, int64_t ldo, int col_tiles, int half,
                          const float* __restrict__ bias, float scale, int exp)
 {
+#if !STPY_LAB
+	exp = 0;          // (timing ablations exist in the lab build only: folds every `exp` test away)
+#endif
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	constexpr int LD = D + 4;             // rows shift by 4 banks: a quarter wave's ds_read_b128 touches every bank once
 	constexpr int F4 = D / 4;
@@ -168,6 +171,9 @@ void rff_stream_f32_kernel(const float* __restrict__ x, int64_t ldx, const float
                            float* __restrict__ out, int64_t ldo, int row_blocks, int cols_per_part, int half,
                            const float* __restrict__ bias, float scale, int exp)
 {
+#if !STPY_LAB
+	exp = 0;          // (timing ablations exist in the lab build only: folds every `exp` test away)
+#endif
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	constexpr int CLD = 36;
 	__shared__ __attribute__((aligned(16))) float smem[4 * 64 * CLD];
@@ -276,6 +282,7 @@ void rff_stream_f32_kernel(const float* __restrict__ x, int64_t ldx, const float
 	}
 }
 
+#if STPY_LAB
 // ---- the same streaming kernel with the MFMA operands SWAPPED (W tile as the "row" operand, x rows as the "column" operand):
 // the accumulator of tile (tn, tm) then holds, in lane (r16, kq), the four CONSECUTIVE features tn*16 + 4 kq .. + 3 of sample
 // tm*16 + r16 -- exactly one 16-byte store per MFMA tile, straight from the registers.  No LDS patch, no ds_write per element,
@@ -287,6 +294,9 @@ void rff_stream_direct_f32_kernel(const float* __restrict__ x, int64_t ldx, cons
                                   float* __restrict__ out, int64_t ldo, int row_blocks, int cols_per_part, int half,
                                   const float* __restrict__ bias, float scale, int exp)
 {
+#if !STPY_LAB
+	exp = 0;          // (timing ablations exist in the lab build only: folds every `exp` test away)
+#endif
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -376,6 +386,7 @@ void rff_stream_direct_f32_kernel(const float* __restrict__ x, int64_t ldx, cons
 		finish(acc1, tiles - 1);
 	}
 }
+#endif  // STPY_LAB
 
 // ---- fp32 embed with the contraction on the bf16 MATRIX cores (d = 64, the shapes of the streaming kernel above, workspace given).
 // Why: v_mfma_f32_16x16x4_f32 runs on the SIMD's own fp32 lanes -- tools/mfma_filler_probe.hip: every VALU instruction next to it costs
@@ -610,16 +621,23 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 			int rc = check_launch("rff_split_w");
 			if (rc) return rc;
 #define STPY_BF3(E) hipLaunchKernelGGL(rff_stream_bf16x3_kernel<E>, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, (const u4v*)work, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale)
+#if STPY_LAB
 			switch (g_gemm_exp) {
 			case 1: STPY_BF3(1); break;
 			case 8: STPY_BF3(8); break;
 			default: STPY_BF3(0); break;
 			}
+#else
+			STPY_BF3(0);
+#endif
 #undef STPY_BF3
 			return check_launch("rff_stream_bf16x3");
 		}
+#if STPY_LAB
 		if (g_rff_tile == 3) hipLaunchKernelGGL(rff_stream_direct_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
-		else hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
+		else
+#endif
+		hipLaunchKernelGGL(rff_stream_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, st, x, ldx, W, ldw, out, ldo, row_blocks, (int)(m / 8), (int)(m / 2), bias, (float)scale, g_gemm_exp);
 		return check_launch("rff_stream_f32");
 	}
 	if (!feat_scale && g_rff_tile && !transposed && (d == 32 || d == 64) && n % 128 == 0 && m % 64 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&

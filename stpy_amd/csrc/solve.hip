@@ -4,6 +4,7 @@
 #include <atomic>
 #include <type_traits>
 
+#include <cstddef>
 #include "common.h"
 
 namespace stpy {
@@ -258,8 +259,7 @@ static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* 
 // G1 is cut into K passes (workspace) so that it runs as several rounds of workgroups and the side
 // stream's kernels get CU slots in between.
 int g_trsm_right_looking = 0;
-int g_trsm_pass_depth = 1024;     // least K depth of one pass
-int g_trsm_wg_target = 2048;      // workgroups a long product is cut into (four rounds of two per CU)
+// g_trsm_pass_depth = 1024: least K depth of one pass;  g_trsm_wg_target = 2048: workgroups a long product is cut into (four rounds of two per CU)
 
 int trsm_auto_nb(int64_t)
 {
@@ -495,6 +495,8 @@ void trsv_bwd_step(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W
 // one lane (sc1 load, s_sleep, bounded), barrier, and read t_j with sc1 loads only (MI355X_MICROARCH.md, "Valid forms":
 // sc1 stores + drained + flag on one side, sc1 poll + barrier + sc1 loads on the other; one workgroup per CU).
 // ------------------------------------------------------------------------------------------
+// ticket / count are zeroed before every launch; `error` is STICKY (set when a hand-off wait gives up, read and cleared by
+// stpy_async_status): a timed-out solve also poisons its output with NaN, so the failure shows in every result derived from it
 struct TrsvSync { unsigned ticket, count, error, pad; };
 int g_trsv_flow = 1;           // stpy_tune key 16: 0 = always the chain of step kernels
 
@@ -505,13 +507,13 @@ __device__ __forceinline__ void store_sc1(T* p, T v) { __hip_atomic_store(p, v, 
 
 template <typename T, bool BACK>
 __global__ __launch_bounds__(256, 1)
-void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W, const T* __restrict__ y, T* out, int nblk, TrsvSync* sy)
+void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict__ W, const T* __restrict__ y, T* out, int nblk, TrsvSync* sy, int fault_ticket)
 {
-	__shared__ int s_k, s_ready;
+	__shared__ int s_k, s_ready, s_failed;
 	__shared__ T yc[IB];
 	__shared__ T red[16][IB + 1];
 	const int tid = threadIdx.x;
-	if (tid == 0) s_k = (int)atomicAdd(&sy->ticket, 1u);
+	if (tid == 0) { s_k = (int)atomicAdd(&sy->ticket, 1u); s_failed = 0; }
 	__syncthreads();
 	const int k = s_k;
 	if (k >= nblk) return;
@@ -550,7 +552,9 @@ void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict_
 				if (dist > 8) __builtin_amdgcn_s_sleep(127); else if (dist > 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
 				c = load_sc1(&sy->count);
 			}
-			if ((int)c <= j) { atomicExch(&sy->error, 1u); c = (unsigned)nblk; }          // give up rather than hang (results are then wrong)
+			// give up rather than hang -- LOUDLY: the sticky error word (stpy_async_status) and, below, NaN in this block of the
+			// output, which every later block and every quantity derived from the solve inherits
+			if ((int)c <= j) { atomicExch(&sy->error, 1u); s_failed = 1; c = (unsigned)nblk; }
 			s_ready = (int)c;
 		}
 		__syncthreads();
@@ -621,6 +625,10 @@ void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict_
 	__syncthreads();
 	// ---- t_i = inverse(L_ii) y_i (forward) or inverse(L_ii)^T y_i (backward), published write-through
 	T* ti = out + (int64_t)i * IB;
+	if (s_failed) {          // (uniform: written before a workgroup barrier every thread has passed) a wait timed out -> poison
+		if (tid < IB) yc[tid] = (T)__builtin_nan("");
+		__syncthreads();
+	}
 	if (!BACK) {
 		T yv[8];
 #pragma unroll
@@ -656,7 +664,29 @@ void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict_
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores ...
 	__syncthreads();                                           // ... before ONE lane publishes the counter
+#if STPY_LAB
+	if (k == fault_ticket) return;          // test hook (stpy_tune key 22): this block is never published -> its successor's wait must time out
+#endif
 	if (tid == 0) store_sc1(&sy->count, (unsigned)(k + 1));
+}
+
+// sticky error word of the vector solves issued on `st`: waits for the stream, returns the word and clears it
+int trsv_async_status(hipStream_t st, int* status)
+{
+	LookAhead* la = nullptr;
+	int rc = lookahead_acquire(st, &la);
+	if (rc) return rc;
+	*status = 0;
+	if (!la->trsv_sync) return 0;
+	unsigned err = 0;
+	if (hipStreamSynchronize(st) != hipSuccess ||
+	    hipMemcpy(&err, (const char*)la->trsv_sync + offsetof(TrsvSync, error), sizeof(err), hipMemcpyDeviceToHost) != hipSuccess ||
+	    (err != 0 && hipMemset((char*)la->trsv_sync + offsetof(TrsvSync, error), 0, sizeof(err)) != hipSuccess)) {
+		set_error("async status: reading the device error word failed");
+		return -1005;
+	}
+	*status = (int)err;
+	return 0;
 }
 
 template <typename T>
@@ -668,7 +698,7 @@ int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int tr
 		int rc = lookahead_acquire(st, &la);
 		if (rc) return rc;
 		if (la->trsv_sync) {
-			if (hipMemsetAsync(la->trsv_sync, 0, sizeof(TrsvSync), st) != hipSuccess) { set_error("trsv: hipMemsetAsync failed"); return -1004; }
+			if (hipMemsetAsync(la->trsv_sync, 0, 2 * sizeof(unsigned), st) != hipSuccess) { set_error("trsv: hipMemsetAsync failed"); return -1004; }          // ticket + count; `error` is sticky
 			const int nblk = (int)(n / IB);
 			// 84 KiB of (unused) dynamic LDS: ONE workgroup per CU, the configuration the sc1 hand-off form is measured for -- and
 			// what the kernel wants anyway (one wave per SIMD, three register images of a block)
@@ -681,8 +711,8 @@ int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int tr
 				if (e != hipSuccess) { set_error("trsv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
 				attr_set[which].store(true, std::memory_order_release);
 			}
-			if (!trans) hipLaunchKernelGGL((trsv_flow_kernel<T, false>), dim3((unsigned)nblk), dim3(256), PAD_LDS, st, L, ldl, winv, (const T*)y, out, nblk, (TrsvSync*)la->trsv_sync);
-			else hipLaunchKernelGGL((trsv_flow_kernel<T, true>), dim3((unsigned)nblk), dim3(256), PAD_LDS, st, L, ldl, winv, (const T*)y, out, nblk, (TrsvSync*)la->trsv_sync);
+			if (!trans) hipLaunchKernelGGL((trsv_flow_kernel<T, false>), dim3((unsigned)nblk), dim3(256), PAD_LDS, st, L, ldl, winv, (const T*)y, out, nblk, (TrsvSync*)la->trsv_sync, g_trsv_fault_ticket);
+			else hipLaunchKernelGGL((trsv_flow_kernel<T, true>), dim3((unsigned)nblk), dim3(256), PAD_LDS, st, L, ldl, winv, (const T*)y, out, nblk, (TrsvSync*)la->trsv_sync, g_trsv_fault_ticket);
 			return check_launch("trsv (flow)");
 		}
 	}

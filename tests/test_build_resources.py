@@ -24,6 +24,17 @@ def test_header_symbols_exported():
 		assert hasattr(lib, name), "libstpy_hip.so lacks %s" % name
 	assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
 	assert lib.stpy_version().startswith(b"stpy_hip")
+	# ... and NOTHING else: the dynamic symbol table of the product library is the header (no internal C++ symbols, no debug
+	# hooks, no kernel handles -- csrc/exports.map), and the experiment knobs are not in it (lab build only)
+	out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+	exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+	assert exported == declared, sorted(exported ^ declared)
+	if not _lib.LIB_PATH.endswith("_lab.so"):
+		assert b"lab" not in lib.stpy_version()
+		for key in (0, 1, 2, 6, 11, 12, 18, 20, 21, 22):
+			assert lib.stpy_tune_get(key) == -1, "experiment knob %d is compiled into the product library" % key
+		for key in (5, 8, 9, 16, 17):
+			assert lib.stpy_tune_get(key) >= 0
 
 
 def test_no_cpu_fallback_without_gpu():
