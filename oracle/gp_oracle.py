@@ -313,6 +313,71 @@ def log_marginal(x, y, spec, s, overrides=None, weight=1.0):
 	return np.array([[0.5 * float((z.T @ z)[0, 0]) + 0.5 * weight * logdet]])
 
 
+def _item_dk(x, name, p):
+	"""(k_i, {param: [dk_i / dparam_m for every component m]}) of one kernel item on x, x -- the items whose kernel functions
+	are torch-differentiable in the reference (kernels.py:368-398 SE, :552-583 ARD, :697-725 additive-group ARD)."""
+	x = np.asarray(x, dtype=np.float64)
+	if name == "squared_exponential":
+		g = float(np.asarray(p.get("gamma", 1.0)).reshape(-1)[0])
+		xs = _cols(x, p.get("group"))
+		sq = ((xs[:, None, :] - xs[None, :, :]) ** 2).sum(-1)
+		k = squared_exponential(x, x, g, p.get("kappa", 1.0), p.get("group"))
+		return k, {"gamma": [k * sq / g ** 3]}
+	if name in ("ard", "ard_additive"):
+		ag = np.asarray(p["ard_gamma"], dtype=np.float64).reshape(-1)
+		xs = _cols(x, p.get("group"))
+		groups = p["groups"] if name == "ard_additive" else [list(range(xs.shape[1]))]
+		k = np.zeros((x.shape[0], x.shape[0]))
+		dk = [np.zeros_like(k) for _ in range(ag.shape[0])]
+		for grp in groups:
+			kg = ard(xs, xs, ag, p.get("kappa", 1.0), grp)
+			k += kg / float(len(groups))
+			for m in grp:
+				dk[m] += kg * (xs[:, None, m] - xs[None, :, m]) ** 2 / ag[m] ** 3 / float(len(groups))
+		return k, {"ard_gamma": dk}
+	raise NotImplementedError("no reference gradient for kernel %r (Matern goes through NumPy in the reference, kernels.py:840-859)" % name)
+
+
+def log_marginal_grad(x, y, spec, s, overrides=None, weight=1.0):
+	"""
+	Value and gradient of gauss_procc.py:631-638 with respect to the lengthscale parameters of every item and the noise level:
+	d/dtheta [1/2 y^T K^-1 y + w/2 log det K] = 1/2 tr((w K^-1 - alpha alpha^T) dK/dtheta)  -- what autograd through the
+	reference's log_marginal yields (estimator.py:156-190 hands exactly that to its optimisers); pinned by golden G14.
+	Items are combined as kernels.py:146-157: dK/dk_i = (value accumulated before item i, if it is joined by "*", else 1)
+	times every later item joined by "*".  Returns (value (1,1), {item index: {param: gradient vector}}, d/ds).
+	"""
+	x = np.asarray(x, dtype=np.float64)
+	y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+	items = []
+	for i, (name, params, op) in enumerate(spec):
+		p = dict(params)
+		if overrides:
+			p.update(overrides.get(str(i), {}))
+		items.append((op,) + _item_dk(x, name, p))
+	# prefix values (before item i) and suffix products (later items joined by "*")
+	acc, prefix = None, []
+	for op, k, _ in items:
+		prefix.append(acc)
+		acc = k if acc is None or op == "-" else (acc + k if op == "+" else acc * k)
+	K = acc.copy()
+	K[np.diag_indices_from(K)] += s * s
+	L = sla.cholesky(K, lower=True, check_finite=False)
+	alpha = sla.cho_solve((L, True), y, check_finite=False)
+	Kinv = sla.cho_solve((L, True), np.eye(K.shape[0]), check_finite=False)
+	G = 0.5 * (weight * Kinv - alpha @ alpha.T)
+	z = sla.solve_triangular(L, y, lower=True, check_finite=False)
+	value = np.array([[0.5 * float((z.T @ z)[0, 0]) + 0.5 * weight * 2.0 * np.sum(np.log(np.diag(L)))]])
+	grads = {}
+	for i, (op, k, dks) in enumerate(items):
+		M = np.ones_like(k) if (op != "*" or prefix[i] is None) else prefix[i]
+		for j in range(i + 1, len(items)):
+			# a later "+" item leaves d(out)/d(k_i) unchanged; a later "*" item multiplies it
+			if items[j][0] == "*":
+				M = M * items[j][1]
+		grads[i] = {name: np.array([float(np.sum(G * M * d)) for d in dl]) for name, dl in dks.items()}
+	return value, grads, float(2.0 * s * np.trace(G))
+
+
 def norm(x, alpha, spec):
 	"""gauss_procc.py:179-184: sqrt(alpha^T k(x,x) alpha)."""
 	a = np.asarray(alpha, dtype=np.float64).reshape(-1, 1)

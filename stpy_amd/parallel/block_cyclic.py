@@ -48,6 +48,7 @@ refuses two ranks on one device -- ``DistributedGaussianProcess`` therefore warn
 on the nccl backend with more than one rank.  DESIGN.md section (f) holds the per-step cost model a measured
 1 / 2 / 4 / 8-GPU curve is to be judged against.
 """
+import contextlib
 import warnings
 import ctypes
 import math
@@ -194,7 +195,7 @@ class HipLocalOps:
 class _Factor:
 	"""The distributed factor of one (x, hyper-parameter) pair: this rank's local blocks of L, the inverse diagonal
 	blocks the solves reuse, and z = L^-1 y in the column distribution."""
-	__slots__ = ("n", "nblk", "nr", "nc", "Aloc", "winv", "zloc", "xd", "kwargs")
+	__slots__ = ("n", "nblk", "nr", "nc", "Aloc", "winv", "zloc", "xd", "kwargs", "NB")
 
 
 class DistributedGaussianProcess:
@@ -205,7 +206,7 @@ class DistributedGaussianProcess:
 	which is how its own overhead is measured)."""
 
 	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", nu=1.5, kernel=None, d=1,
-				 grid=None, nb_dist=1024, ops=None, group=None, force_path=False):
+				 grid=None, nb_dist=None, ops=None, group=None, force_path=False, transport="auto", col_exchange="allgather", audit=False):
 		self.s = s
 		self.d = d
 		self.kernel_object = kernel if kernel is not None else KernelFunction(kernel_name=kernel_name, gamma=gamma, nu=nu, kappa=kappa, d=d)
@@ -217,9 +218,20 @@ class DistributedGaussianProcess:
 		self.Pr, self.Pc = grid if grid is not None else default_grid(self.world)
 		if self.Pr * self.Pc != self.world:
 			raise ValueError("process grid %dx%d does not match world size %d" % (self.Pr, self.Pc, self.world))
-		if nb_dist % IB != 0:
-			raise ValueError("nb_dist must be a multiple of %d" % IB)
-		self.NB = nb_dist
+		# distribution block: None = by the problem size at fit time (auto_nb_dist: 2048 from N = 131 072 on -- half the block steps,
+		# i.e. half the latency-bound panel chains and collectives, and K = 2048 trailing updates -- 1024 below)
+		if nb_dist is not None and (nb_dist <= 0 or nb_dist % IB != 0):
+			raise ValueError("nb_dist must be a positive multiple of %d" % IB)
+		self._nb_dist_arg = nb_dist
+		self.NB = nb_dist if nb_dist is not None else 1024
+		if transport not in ("auto", "collective", "fanout"):
+			raise ValueError("transport: 'auto', 'collective' (RCCL broadcast) or 'fanout' (root -> every peer point to point)")
+		if col_exchange not in ("allgather", "bcast"):
+			raise ValueError("col_exchange: 'allgather' (one collective per step) or 'bcast' (one broadcast per process row)")
+		self._transport_arg, self.col_exchange = transport, col_exchange
+		self.transport = "collective"
+		self.audit = [] if audit else None          # per collective: (communicator, op, root, bytes, logical stream) -- tests/test_block_cyclic_cpu.py
+		self._lstream = "main"
 		self.nb = 0
 		self.fitted = False
 		self.clamp_variance = False
@@ -260,9 +272,22 @@ class DistributedGaussianProcess:
 				raise
 			# (raised identically on every rank before any communicator exists, so the retry stays collective)
 			self.row_groups, self.col_groups = make_groups({})
+		self._group_names = {}
+		for r, g in enumerate(self.row_groups):
+			self._group_names[id(g)] = "row%d" % r
+		for c, g in enumerate(self.col_groups):
+			self._group_names[id(g)] = "col%d" % c
 		# RCCL creates a communicator at the FIRST collective of a group.  Do that here, in one fixed order (own process row, then
 		# own process column: the row groups are disjoint, so are the column groups -- no cyclic wait), instead of in the middle of
 		# the first panel step where ranks reach their groups at different points of the schedule.
+		# Transport of the panel broadcasts.  xGMI is point to point (every GPU pair has its own link), so a root that sends its
+		# panel to each peer separately -- one batched group of isend / irecv, which RCCL runs concurrently -- keeps 1 ... P-1 links
+		# busy at once where a ring broadcast is bound by one link per hop.  "auto" takes the fan-out only on RCCL and only when
+		# every visible device pair has peer access; gloo (CPU tests, one-GPU rehearsal) keeps broadcasts unless asked.
+		if self._transport_arg == "fanout":
+			self.transport = "fanout"
+		elif self._transport_arg == "auto" and dist.get_backend() == "nccl" and self.world > 1 and self._peer_access_everywhere():
+			self.transport = "fanout"
 		if dist.get_backend() == "nccl" and self.world > 1:
 			token = torch.zeros(1, dtype=torch.float32, device=self.ops.device)
 			if self.Pc > 1:
@@ -271,6 +296,32 @@ class DistributedGaussianProcess:
 				dist.all_reduce(token, group=self.col_groups[self.myc])
 			dist.all_reduce(token)
 			torch.cuda.synchronize()
+
+	@staticmethod
+	def auto_nb_dist(n):
+		"""Distribution block when the caller gave none: 2048 from N = 131 072 on, 1024 below."""
+		return 2048 if n >= 131072 else 1024
+
+	@staticmethod
+	def _peer_access_everywhere():
+		try:
+			nd = torch.cuda.device_count()
+			return nd > 1 and all(torch.cuda.can_device_access_peer(a, b) for a in range(nd) for b in range(nd) if a != b)
+		except Exception:          # noqa: BLE001
+			return False
+
+	@contextlib.contextmanager
+	def _on(self, name, stream):
+		"""Everything issued inside runs on `stream` (None on CPU tensors) and is logged under the logical stream `name`."""
+		prev, self._lstream = self._lstream, name
+		try:
+			if stream is not None:
+				with torch.cuda.stream(stream):
+					yield
+			else:
+				yield
+		finally:
+			self._lstream = prev
 
 	# ------------------------------------------------------------------ index arithmetic
 	def _rank_of(self, r, c):
@@ -308,22 +359,56 @@ class DistributedGaussianProcess:
 		self.stats[kind] += t.numel() * t.element_size()
 		self.stats["collectives"] += 1
 
+	def _log(self, group, op, root, t):
+		"""Order audit: what an RCCL communicator needs to see identically on every member -- the sequence of (operation, root,
+		bytes) -- plus the logical stream it was issued from.  A mismatch passes on host-staged gloo and hangs on RCCL."""
+		if self.audit is not None:
+			name = "world" if group is None else self._group_names[id(group)]
+			self.audit.append((name, op, int(root), int(t.numel() * t.element_size()), self._lstream))
+
+	def _members(self, group):
+		return list(range(self.world)) if group is None else dist.get_process_group_ranks(group)
+
+	def _fanout(self, buf, src, group):
+		"""root -> every other member, point to point, as ONE batched group (RCCL: concurrent sends on distinct links)."""
+		me = dist.get_rank()
+		if me == src:
+			ops = [dist.P2POp(dist.isend, buf, peer, group) for peer in self._members(group) if peer != src]
+		else:
+			ops = [dist.P2POp(dist.irecv, buf, src, group)]
+		for w in dist.batch_isend_irecv(ops):
+			w.wait()
+
 	def _bcast(self, t, src, group, size):
 		if size <= 1:
 			return
 		self._count(t, "bcast_bytes")
+		self._log(group, "bcast/" + self.transport, src, t)
+		send = self._fanout if self.transport == "fanout" else (lambda b, s_, g: dist.broadcast(b, src=s_, group=g))
 		if self._staged(t):
 			h = self._to_host(t)
-			dist.broadcast(h, src=src, group=group)
+			send(h, src, group)
 			if dist.get_rank() != src:
 				self._from_host(t, h)
 		else:
-			dist.broadcast(t, src=src, group=group)
+			send(t, src, group)
+
+	def _allgather(self, out, mine, group, size):
+		"""out[(member index)] <- every member's `mine` (equal sizes); one collective."""
+		self._count(out, "bcast_bytes")
+		self._log(group, "allgather", -1, mine)
+		if self._staged(mine):
+			hm, ho = self._to_host(mine), torch.empty(out.shape, dtype=out.dtype, device="cpu", pin_memory=True)
+			dist.all_gather_into_tensor(ho.reshape(-1), hm.reshape(-1), group=group)
+			self._from_host(out, ho)
+		else:
+			dist.all_gather_into_tensor(out.reshape(-1), mine.reshape(-1), group=group)
 
 	def _reduce_sum(self, t, dst, group, size):
 		if size <= 1:
 			return
 		self._count(t, "reduce_bytes")
+		self._log(group, "reduce", dst, t)
 		if self._staged(t):
 			h = self._to_host(t)
 			dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
@@ -336,6 +421,7 @@ class DistributedGaussianProcess:
 		if self.world <= 1:
 			return
 		self._count(t, "reduce_bytes")
+		self._log(None, "allreduce", -1, t)
 		if self._staged(t):
 			h = self._to_host(t)
 			dist.all_reduce(h, op=op)
@@ -417,10 +503,13 @@ class DistributedGaussianProcess:
 
 	def _factorize(self, xd, yd, kwargs):
 		"""Gram fill + block-cyclic Cholesky + z = L^-1 y for the kernel parameters in ``kwargs`` (None: the stored ones)."""
-		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
 		n = xd.shape[0]
+		if self._nb_dist_arg is None:
+			self.NB = self.auto_nb_dist(n)          # (a function of N alone: the same on every rank)
+		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
 		f = _Factor()
 		f.n, f.xd, f.kwargs = n, xd, kwargs
+		f.NB = NB
 		nblk = (n + NB - 1) // NB
 		f.nblk = nblk
 		nr = (nblk - myr + Pr - 1) // Pr if nblk > myr else 0         # local block rows / cols
@@ -502,23 +591,49 @@ class DistributedGaussianProcess:
 			# column operand: L_JK for this rank's local block columns J > K
 			# The wanted J (J % Pc == myc, J % Pr == rp, J > K) form an arithmetic progression with stride
 			# lcm(Pr, Pc), so source and destination are strided slices: no index tensors, no host sync.
+			prog = []
 			for rp in range(Pr):
 				J0 = next((J for J in range(K + 1, min(nblk, K + 1 + lcm)) if J % Pc == myc and J % Pr == rp), None)
-				if J0 is None:
-					continue
-				cnt = (nblk - 1 - J0) // lcm + 1
-				i0p = self._first_local_above(K, rp, Pr)
-				a, sa = J0 // Pr - i0p, lcm // Pr
+				prog.append(None if J0 is None else (J0, (nblk - 1 - J0) // lcm + 1))
+			def src_of(rp):          # (this rank's contribution: blocks of prow)
+				J0, cnt = prog[rp]
+				a, sa = J0 // Pr - self._first_local_above(K, rp, Pr), lcm // Pr
+				return prow.reshape(-1, NB, NB)[a:a + (cnt - 1) * sa + 1:sa]
+			def dst_of(rp):
+				J0, cnt = prog[rp]
 				b, sb = J0 // Pc - j0, lcm // Pc
-				dst = pcol.reshape(-1, NB, NB)[b:b + (cnt - 1) * sb + 1:sb]
-				if myr == rp:
-					src = prow.reshape(-1, NB, NB)[a:a + (cnt - 1) * sa + 1:sa]
-					buf = src if sa == 1 else src.contiguous()
-				else:
-					buf = dst if sb == 1 else ops.empty(cnt * NB, NB).reshape(cnt, NB, NB)
-				self._bcast(buf, self._rank_of(rp, myc), self.col_groups[myc], Pr)
-				if buf is not dst:
-					dst.copy_(buf)
+				return pcol.reshape(-1, NB, NB)[b:b + (cnt - 1) * sb + 1:sb]
+			if Pr == 1:
+				if prog[0] is not None:
+					dst_of(0).copy_(src_of(0))
+			elif self.col_exchange == "allgather":
+				# ONE collective per step and column group: every member contributes the blocks it holds (padded to the longest
+				# progression) and receives everybody's -- on two process rows a simultaneous exchange in both directions of the
+				# link instead of two one-way broadcasts in sequence
+				cmax = max((pg[1] for pg in prog if pg is not None), default=0)
+				if cmax > 0:
+					mine = ops.empty(cmax, NB, NB)
+					if prog[myr] is not None:
+						mine[:prog[myr][1]].copy_(src_of(myr))
+					allb = ops.empty(Pr, cmax, NB, NB)
+					self._allgather(allb, mine, self.col_groups[myc], Pr)
+					for rp in range(Pr):
+						if prog[rp] is not None:
+							dst_of(rp).copy_(allb[rp, :prog[rp][1]])
+			else:
+				for rp in range(Pr):
+					if prog[rp] is None:
+						continue
+					cnt = prog[rp][1]
+					dst = dst_of(rp)
+					if myr == rp:
+						src = src_of(rp)
+						buf = src if src.is_contiguous() else src.contiguous()
+					else:
+						buf = dst if dst.is_contiguous() else ops.empty(cnt * NB, NB).reshape(cnt, NB, NB)
+					self._bcast(buf, self._rank_of(rp, myc), self.col_groups[myc], Pr)
+					if buf is not dst:
+						dst.copy_(buf)
 			return i0, j0, prow, pcol
 
 		# One block column of look-ahead: after panel K is in place, the local update of block column
@@ -546,18 +661,18 @@ class DistributedGaussianProcess:
 			# the remaining columns: compute only, enqueued before the (possibly host-blocking) collectives below
 			if rows_below > 0 and nc - j1 > 0:
 				ops.gemm_nt(prow, pcol[(j1 - j0) * NB:], Aloc[i0 * NB:, j1 * NB:], 1, bc=(NB, Pr, Pc, myr, myc, i0, j1))
-			if on_gpu:
-				with torch.cuda.stream(side):
+			with self._on("side", side):
+				if on_gpu:
 					side.wait_event(ev_col)
-					ops.beside_update(True)
-					try:
-						cur = panel_step(K + 1, (K + 1) % 2)
-					finally:
-						ops.beside_update(False)
+				ops.beside_update(True)
+				try:
+					cur = panel_step(K + 1, (K + 1) % 2)
+				finally:
+					ops.beside_update(False)
+				if on_gpu:
 					ev_panel.record(side)
+			if on_gpu:
 				main.wait_event(ev_panel)
-			else:
-				cur = panel_step(K + 1, (K + 1) % 2)
 		bad = bad[0]
 
 		self._allreduce(bad, dist.ReduceOp.MAX)
@@ -582,7 +697,7 @@ class DistributedGaussianProcess:
 		column.  Look-ahead: the terms J <= K-1 of block K+1's sum are formed on the side stream while block K's reduce /
 		solve / broadcast chain runs; only the J = K term is added between the chains.  S lives in two preallocated slots.
 		"""
-		ops, NB, Pr, Pc, myr, myc = self.ops, self.NB, self.Pr, self.Pc, self.myr, self.myc
+		ops, NB, Pr, Pc, myr, myc = self.ops, f.NB, self.Pr, self.Pc, self.myr, self.myc
 		Aloc, n, nblk = f.Aloc, f.n, f.nblk
 		m = rhs_full.shape[0] if rhs_full is not None else xtest.shape[0]
 		Xloc = ops.zeros(m, max(f.nc * NB, 1))
@@ -611,12 +726,12 @@ class DistributedGaussianProcess:
 				jn = self._count_local_below(K, myc, Pc)             # local blocks with J <= K-1
 				if on_gpu:
 					ev_a.record(main)
-					with torch.cuda.stream(side):
+				with self._on("bulk", side):
+					if on_gpu:
 						side.wait_event(ev_a)
-						partial(K + 1, (K + 1) % 2, 0, jn, True)
-						ev_b.record(side)
-				else:
 					partial(K + 1, (K + 1) % 2, 0, jn, True)
+					if on_gpu:
+						ev_b.record(side)
 			if myr == kr:
 				# the one term the look-ahead could not cover: J = K-1 (if this rank holds that block column)
 				if K >= 1 and (K - 1) % Pc == myc:
@@ -672,7 +787,7 @@ class DistributedGaussianProcess:
 		xt = ops.to_device(xtest)
 		m = xt.shape[0]
 		Xloc = self._solve_rows(f, None, xt)
-		Xl = Xloc[:, :f.nc * self.NB]
+		Xl = Xloc[:, :f.nc * f.NB]
 		red = ops.empty(2, m)
 		ops.row_sums(Xl, f.zloc.reshape(-1), out=red)
 		self._allreduce(red, dist.ReduceOp.SUM)
@@ -724,7 +839,7 @@ class DistributedGaussianProcess:
 				Lkk, _ = f.winv[K]
 				acc[0] += ops.logdet(Lkk)
 		if self.myr == 0 and f.nc > 0:
-			z = f.zloc[:, :f.nc * self.NB]
+			z = f.zloc[:, :f.nc * f.NB]
 			acc[1] = ops.row_sums(z, z.reshape(-1))[1][0]
 		self._allreduce(acc, dist.ReduceOp.SUM)
 		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())

@@ -417,6 +417,51 @@ def main():
 	save("G13_hermite_features", x=x, y=y, xtest=xtest, gamma=np.array(0.5), kappa=np.array(1.2), s=np.array(0.15), lam=np.array(1.0), m=np.array(emb.get_m()),
 		 mu=N(mu), std=N(std), mu_exact_gp=N(mu_gp), std_exact_gp=N(std_gp))
 
+	# ---------------------------------------------------------------- G14: gradients of log_marginal
+	# autograd THROUGH THE REFERENCE's own GaussianProcess.log_marginal (gauss_procc.py:497-504 -> :631-638: Gram by the kernel's
+	# torch ops, slogdet + solve), the function estimator.py:156-190 hands to its optimisers.  Differentiable there: SE gamma, ARD
+	# ard_gamma (also with additive groups), sums of such items, and the noise level when self.s is a tensor.  The Matern kernels
+	# go through NumPy (kernels.py:840-859) and carry no gradient in the reference.
+	rng14 = np.random.RandomState(20241114)
+	Ntr, d = 200, 3
+	x = rng14.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(2 * x[:, :1]) + 0.5 * x[:, 1:2] * x[:, 2:3] + 0.1 * rng14.normal(size=(Ntr, 1))
+	s14 = 0.15
+	ag = np.array([0.6, 1.1, 1.7])
+	groups14 = [[0], [1, 2]]
+	out = {}
+
+	def grad_case(tag, make_kernel, leaves, X_of, s_leaf=False):
+		for w in (1.0, 0.5):
+			GP = GaussianProcess(kernel=make_kernel(), s=s14, d=d)
+			GP.fit_gp(T(x), T(y))
+			lv = [torch.tensor(np.atleast_1d(v), dtype=torch.float64, requires_grad=True) for v in leaves]
+			if s_leaf:
+				sv = torch.tensor(s14, dtype=torch.float64, requires_grad=True)
+				GP.s = sv
+			f = GP.log_marginal(GP.kernel_object, X_of(lv), w)
+			f.backward()
+			sfx = "_w%s" % str(w).replace(".", "")
+			out[tag + sfx + "_value"] = N(f)
+			for i, v in enumerate(lv):
+				out[tag + sfx + "_grad%d" % i] = N(v.grad)
+			if s_leaf:
+				out[tag + sfx + "_grad_s"] = N(sv.grad)
+		for i, v in enumerate(leaves):
+			out[tag + "_leaf%d" % i] = np.atleast_1d(np.asarray(v, dtype=np.float64))
+
+	grad_case("se", lambda: KernelFunction(kernel_name="squared_exponential", gamma=0.9, kappa=1.3, d=d), [0.7],
+			  lambda v: {'0': {'gamma': v[0]}})
+	grad_case("se_noise", lambda: KernelFunction(kernel_name="squared_exponential", gamma=0.9, kappa=1.3, d=d), [0.7],
+			  lambda v: {'0': {'gamma': v[0]}}, s_leaf=True)
+	grad_case("ard", lambda: KernelFunction(kernel_name="ard", ard_gamma=T(ag), kappa=0.8, d=d), [ag * 1.1],
+			  lambda v: {'0': {'ard_gamma': v[0]}})
+	grad_case("ard_groups", lambda: KernelFunction(kernel_name="ard", ard_gamma=T(ag), kappa=1.1, d=d, groups=groups14), [ag * 0.9],
+			  lambda v: {'0': {'ard_gamma': v[0]}})
+	grad_case("sum", lambda: KernelFunction(kernel_name="squared_exponential", gamma=0.9, kappa=1.3, d=d) + KernelFunction(kernel_name="ard", ard_gamma=T(ag), kappa=0.8, d=d),
+			  [0.7, ag * 1.2], lambda v: {'0': {'gamma': v[0]}, '1': {'ard_gamma': v[1]}})
+	save("G14_lml_grad", x=x, y=y, s=np.array(s14), ard_gamma=ag, groups_flat=np.array([0, -1, 1, 2]), **out)
+
 	# ---------------------------------------------------------------- B1: beta() and norm() (gauss_procc.py:179-196)
 	rng3 = np.random.RandomState(20241103)
 	x = rng3.uniform(-1, 1, size=(14, 2)); y = np.sin(x.sum(axis=1, keepdims=True)) + 0.05 * rng3.normal(size=(14, 1))

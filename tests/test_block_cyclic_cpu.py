@@ -30,7 +30,7 @@ def _data(n, d, m, seed=7):
 	return x, y, xt
 
 
-def _worker(rank, world, port, grid, n, d, m, nb_dist, kernel_name, nu, q):
+def _worker(rank, world, port, grid, n, d, m, nb_dist, kernel_name, nu, q, opts=None):
 	os.environ["MASTER_ADDR"] = "127.0.0.1"
 	os.environ["MASTER_PORT"] = str(port)
 	dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,10 +40,17 @@ def _worker(rank, world, port, grid, n, d, m, nb_dist, kernel_name, nu, q):
 		from tests.cpu_local_ops import CpuLocalOps
 		x, y, xt = _data(n, d, m)
 		gp = DistributedGaussianProcess(gamma=1.3, s=0.2, kappa=1.1, kernel_name=kernel_name, nu=nu, d=d, grid=grid,
-										nb_dist=nb_dist, ops=CpuLocalOps())
+										nb_dist=nb_dist, ops=CpuLocalOps(), **(opts or {}))
 		gp.fit_gp(torch.from_numpy(x), torch.from_numpy(y))
 		mu, std = gp.mean_std(torch.from_numpy(xt))
 		lml = gp.log_marginal()
+		if opts and opts.get("audit"):
+			# order audit: every member of a communicator must have issued the identical sequence of (op, root, bytes, stream)
+			logs = [None] * world
+			dist.all_gather_object(logs, (gp.Pr, gp.Pc, list(gp.audit)))
+			if rank == 0:
+				q.put((mu.numpy(), std.numpy(), lml.numpy(), logs, dict(gp.stats)))
+			return
 		# the wider estimator surface: full covariance, chunked prediction, kwargs overrides, add_data_point
 		mu_f, cov = gp.mean_std(torch.from_numpy(xt[:11]), full=True)
 		gp.max_size = 16
@@ -109,6 +116,68 @@ def test_block_cyclic_matches_oracle(world, grid, n, nb_dist, kernel_name, nu):
 	mu_ao, std_ao = O.mean_std(x2, L2, alpha2, xt[5:], spec)
 	assert rel_err(mu_a, mu_ao) < 1e-10 and rel_err(std_a, std_ao) < 1e-9
 	assert stats["collectives"] > 0 and stats["bcast_bytes"] > 0
+
+
+@pytest.mark.parametrize("world,grid,n", [(2, (1, 2), 520), (2, (2, 1), 520), (4, (2, 2), 900), (6, (2, 3), 1100), (6, (3, 2), 1100), (8, (2, 4), 1700), (8, (4, 2), 1300)])
+@pytest.mark.parametrize("opts", [{"transport": "collective", "col_exchange": "allgather"}, {"transport": "fanout", "col_exchange": "allgather"},
+								  {"transport": "collective", "col_exchange": "bcast"}, {"transport": "fanout", "col_exchange": "bcast"}],
+						 ids=["bcast+allgather", "fanout+allgather", "bcast+bcast", "fanout+bcast"])
+def test_collective_order_audit(world, grid, n, opts):
+	"""What hangs on RCCL and passes on host-staged gloo is a member of a communicator issuing a different sequence of collectives
+	than its peers.  Every rank logs, per communicator (process row, process column, world), the sequence of (operation, root,
+	bytes, issuing logical stream) of a fit + predict + log-marginal; the sequences of all members of a communicator must be
+	identical, for both transports (RCCL broadcast / point-to-point fan-out) and both forms of the column exchange.  The
+	result is checked against the oracle as well, so each option is also a parity case."""
+	d, m = 3, 29
+	ctx = mp.get_context("spawn")
+	q = ctx.SimpleQueue()
+	port = _free_port()
+	o = dict(opts, audit=True)
+	procs = [ctx.Process(target=_worker, args=(r, world, port, grid, n, d, m, 128, "squared_exponential", 1.5, q, o)) for r in range(world)]
+	for p in procs:
+		p.start()
+	for p in procs:
+		p.join(timeout=300)
+		if p.is_alive():
+			p.terminate()
+	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+	mu, std, lml, logs, stats = q.get()
+	Pr, Pc = logs[0][0], logs[0][1]
+	assert (Pr, Pc) == tuple(grid)
+	members = {"world": list(range(world))}
+	for r in range(Pr):
+		members["row%d" % r] = [r * Pc + c for c in range(Pc)]
+	for c in range(Pc):
+		members["col%d" % c] = [r * Pc + c for r in range(Pr)]
+	seen = 0
+	for name, ranks in members.items():
+		seqs = [[e[1:] for e in logs[r][2] if e[0] == name] for r in ranks]
+		for r, sq in zip(ranks[1:], seqs[1:]):
+			assert sq == seqs[0], "communicator %s: rank %d issued a different sequence than rank %d (first difference at %s)" % (
+				name, r, ranks[0], next((i for i, (a, b) in enumerate(zip(sq, seqs[0])) if a != b), min(len(sq), len(seqs[0]))))
+		seen += len(seqs[0])
+		# no rank logged a communicator it is not a member of
+		for r in range(world):
+			if r not in ranks:
+				assert not [e for e in logs[r][2] if e[0] == name]
+	assert seen > 0
+	# the look-ahead really issues collectives from both logical streams (fit) -- the ordering the audit is about
+	streams = {e[4] for e in logs[0][2]}
+	assert "side" in streams and "main" in streams
+	kinds = {e[1] for lg in logs for e in lg[2]}
+	assert ("allgather" in kinds) == (opts["col_exchange"] == "allgather" and Pr > 1)
+	assert any(k.startswith("bcast/" + opts["transport"]) for k in kinds)
+	x, y, xt = _data(n, d, m)
+	spec = [("squared_exponential", {"gamma": 1.3, "kappa": 1.1}, "-")]
+	L, alpha = O.fit(x, y, spec, 0.2)
+	mu_o, std_o = O.mean_std(x, L, alpha, xt, spec)
+	assert rel_err(mu, mu_o) < 1e-10 and rel_err(std, std_o) < 1e-10
+	assert abs(lml[0, 0] - O.log_marginal(x, y, spec, 0.2)[0, 0]) / abs(lml[0, 0]) < 1e-10
+
+
+def test_auto_nb_dist():
+	from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
+	assert [DistributedGaussianProcess.auto_nb_dist(n) for n in (4096, 65536, 131071, 131072, 262144)] == [1024, 1024, 1024, 2048, 2048]
 
 
 def test_default_grid():

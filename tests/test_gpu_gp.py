@@ -402,6 +402,46 @@ def test_log_marginal_gradient_isotropic(S, name, kind, nu):
 		assert abs(float(g.grad) - float(gr.grad)) / abs(float(gr.grad)) < 1e-7
 
 
+def test_log_marginal_gradient_pinned_to_reference(S):
+	"""SURVEY section 8f rank 1, pinned: value and gradient of GaussianProcess.log_marginal on the HIP path against golden G14 --
+	autograd through the REFERENCE's own log_marginal (gauss_procc.py:631-638, as estimator.py:156-190 drives it) for SE gamma,
+	ARD ard_gamma, additive-group ARD, a sum of two items and the noise level, at weights 1 and 0.5.  Value <= 1e-8, gradient
+	<= 1e-7.  (The Matern kernels have no gradient in the reference -- kernels.py:840-859 goes through NumPy -- so their device
+	gradients stay checked against the torch restatement above, which this fixture in turn validates on the SE / ARD cases.)"""
+	g = golden("G14_lml_grad")
+	x, y, s0 = T(g["x"]), T(g["y"]), float(g["s"])
+	d = x.shape[1]
+	ag = torch.from_numpy(g["ard_gamma"])
+	KF = S.KernelFunction
+	cases = {
+		"se": (lambda: KF(kernel_name="squared_exponential", gamma=0.9, kappa=1.3, d=d), lambda v: {'0': {'gamma': v[0]}}, False),
+		"se_noise": (lambda: KF(kernel_name="squared_exponential", gamma=0.9, kappa=1.3, d=d), lambda v: {'0': {'gamma': v[0]}}, True),
+		"ard": (lambda: KF(kernel_name="ard", ard_gamma=ag.clone(), kappa=0.8, d=d), lambda v: {'0': {'ard_gamma': v[0]}}, False),
+		"ard_groups": (lambda: KF(kernel_name="ard", ard_gamma=ag.clone(), kappa=1.1, d=d, groups=[[0], [1, 2]]), lambda v: {'0': {'ard_gamma': v[0]}}, False),
+		"sum": (lambda: KF(kernel_name="squared_exponential", gamma=0.9, kappa=1.3, d=d) + KF(kernel_name="ard", ard_gamma=ag.clone(), kappa=0.8, d=d),
+				lambda v: {'0': {'gamma': v[0]}, '1': {'ard_gamma': v[1]}}, False),
+	}
+	for tag, (mk, X_of, s_leaf) in cases.items():
+		nleaf = len([k for k in g if k.startswith(tag + "_leaf")])
+		for w, sfx in ((1.0, "_w10"), (0.5, "_w05")):
+			GP = S.GaussianProcess(kernel=mk(), s=s0, d=d)
+			GP.fit_gp(x, y)
+			lv = [torch.from_numpy(g["%s_leaf%d" % (tag, i)]).clone().requires_grad_(True) for i in range(nleaf)]
+			if s_leaf:
+				sv = torch.tensor(s0, dtype=torch.float64, requires_grad=True)
+				GP.s = sv
+			f = GP.log_marginal(GP.kernel_object, X_of(lv), w)
+			assert tuple(f.shape) == (1, 1)
+			f.backward()
+			ref = g[tag + sfx + "_value"].ravel()[0]
+			assert abs(float(f.detach()) - ref) / abs(ref) < 1e-8, (tag, w)
+			for i, v in enumerate(lv):
+				assert rel_err(N(v.grad), g[tag + sfx + "_grad%d" % i]) < 1e-7, (tag, w, i, N(v.grad), g[tag + sfx + "_grad%d" % i])
+			if s_leaf:
+				want = g[tag + sfx + "_grad_s"].ravel()[0]
+				assert abs(float(sv.grad) - want) / abs(want) < 1e-7, (tag, w)
+
+
 def _tk(x, kind, ls, kappa, cols=None):
 	"""one kernel matrix in torch CPU autograd (same forms as _torch_lml)"""
 	xs = (x if cols is None else x[:, cols]) / ls

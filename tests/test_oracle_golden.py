@@ -170,6 +170,44 @@ def test_G6_override_lml():
 	assert abs(g["lml_default"] - g["lml_estimator"]) / abs(g["lml_default"]) < 1e-11
 
 
+G14_CASES = {
+	# tag: (oracle spec with the STORED parameters, overrides builder from the leaves, [(item, param)] of each leaf)
+	"se": ([("squared_exponential", {"gamma": 0.9, "kappa": 1.3}, "-")], lambda lv: {'0': {'gamma': float(lv[0][0])}}, [(0, "gamma")]),
+	"se_noise": ([("squared_exponential", {"gamma": 0.9, "kappa": 1.3}, "-")], lambda lv: {'0': {'gamma': float(lv[0][0])}}, [(0, "gamma")]),
+	"ard": ([("ard", {"ard_gamma": None, "kappa": 0.8}, "-")], lambda lv: {'0': {'ard_gamma': lv[0]}}, [(0, "ard_gamma")]),
+	"ard_groups": ([("ard_additive", {"ard_gamma": None, "kappa": 1.1, "groups": [[0], [1, 2]]}, "-")], lambda lv: {'0': {'ard_gamma': lv[0]}}, [(0, "ard_gamma")]),
+	"sum": ([("squared_exponential", {"gamma": 0.9, "kappa": 1.3}, "-"), ("ard", {"ard_gamma": None, "kappa": 0.8}, "+")],
+			lambda lv: {'0': {'gamma': float(lv[0][0])}, '1': {'ard_gamma': lv[1]}}, [(0, "gamma"), (1, "ard_gamma")]),
+}
+
+
+def g14_cases():
+	g = golden("G14_lml_grad")
+	for tag, (spec, ov_of, where) in G14_CASES.items():
+		spec = [(n, dict(p, ard_gamma=g["ard_gamma"]) if "ard_gamma" in p else dict(p), op) for n, p, op in spec]
+		leaves = [g["%s_leaf%d" % (tag, i)] for i in range(len(where))]
+		for w, sfx in ((1.0, "_w10"), (0.5, "_w05")):
+			ref = {"value": g[tag + sfx + "_value"], "grads": [g[tag + sfx + "_grad%d" % i] for i in range(len(where))],
+				   "grad_s": g[tag + sfx + "_grad_s"] if (tag + sfx + "_grad_s") in g else None}
+			yield tag, w, spec, ov_of(leaves), where, leaves, ref, g
+
+
+@pytest.mark.parametrize("case", list(g14_cases()), ids=lambda c: "%s-w%s" % (c[0], c[1]))
+def test_G14_log_marginal_gradient(case):
+	"""value and gradient of log_marginal from autograd THROUGH THE REFERENCE (SE gamma, ARD ard_gamma,
+	additive-group ARD, a sum of items, the noise level) against the oracle's analytic trace formula."""
+	tag, w, spec, ov, where, leaves, ref, g = case
+	val, grads, gs = O.log_marginal_grad(g["x"], g["y"], spec, float(g["s"]), overrides=ov, weight=w)
+	assert abs(val[0, 0] - ref["value"].ravel()[0]) / abs(ref["value"].ravel()[0]) < 1e-10
+	for (item, param), want in zip(where, ref["grads"]):
+		got = grads[item][param]
+		if param == "gamma":
+			assert got.shape == (1,)
+		assert rel_err(got, want.ravel()) < 1e-8, (tag, param, got, want)
+	if ref["grad_s"] is not None:
+		assert abs(gs - ref["grad_s"].ravel()[0]) / abs(ref["grad_s"].ravel()[0]) < 1e-8
+
+
 def test_G7_full_prior_execute():
 	g = golden("G7_full_prior")
 	s = float(g["s"])

@@ -4,6 +4,10 @@ O=$R/gpurun_out/r3a
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
+python3 -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "pytest rc $?" >> $O/gputests.log
+tail -3 $O/gputests.log
+STPY_HIP_LIB=lab python3 -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "trsv or strip or beside" > $O/gputests_lab.log 2>&1; echo "pytest rc $?" >> $O/gputests_lab.log
+tail -3 $O/gputests_lab.log
 rocprofv3 --kernel-trace --output-format csv -d $O/kt16 -o p -- python3 tools/potrf_only.py 16384 > $O/kt16.log 2>&1 || exit 1
 f=$(ls $O/kt16/*/*kernel_trace.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(find $O/kt16 -name '*kernel_trace.csv' | head -1)
 python3 tools/trace_union.py $f --steps 3 --flops-per-step 1.466e12 > $O/kt16_union.txt 2>&1
@@ -20,6 +24,5 @@ for r in sel:
     s=int(r['Start_Timestamp'])-t0; e=int(r['End_Timestamp'])-t0
     print(r.get('Queue_Id','?'), nm, s/1e3, (e-s)/1e3, r.get('Grid_Size','?'), r.get('Workgroup_Size','?'))
 PY
-python3 tools/potrf_sweep.py "8192,16384,32768" "0=40000" > $O/potrf_sweep.log 2>&1
-python3 -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "pytest rc $?" >> $O/gputests.log
-tail -3 $O/gputests.log
+STPY_HIP_LIB=lab python3 tools/potrf_sweep.py "8192,16384,32768" "0=40000" > $O/potrf_sweep.log 2>&1
+cat $O/potrf_sweep.log
