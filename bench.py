@@ -235,6 +235,49 @@ def extra_configs(dev, lib):
 	del work
 	del z
 	torch.cuda.empty_cache()
+
+	# KF: KernelizedFeatures at BASELINE config 5's data shape with m = 8192 features, fp32: the normal
+	# equations V = Phi^T Phi + s^2 lam I accumulated over row slabs (Phi never materialised: it would be 8.6 GB here, 34 GB at
+	# m = 32 768), Cholesky of V, prediction at M = 4096 points.  Bound: fp32 MFMA on N m^2 (lower-triangular SYRK) + m^3/3 + M m^2.
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	n, d, m, M = 262144, 64, 8192, 4096
+	gen = torch.Generator().manual_seed(1238)
+	xk = torch.rand(n, d, generator=gen, dtype=torch.float32).to(dev)
+	yk = torch.sin(xk[:, :4].sum(dim=1, keepdim=True)) + 0.1 * torch.randn(n, 1, generator=torch.Generator().manual_seed(1239), dtype=torch.float32).to(dev)
+	xtk = torch.rand(M, d, generator=torch.Generator().manual_seed(1240), dtype=torch.float32).to(dev)
+	np.random.seed(1238)
+	embk = RFFEmbedding(gamma=math.sqrt(d), m=m, d=d)
+	embk.W = embk.W.float()
+	kf = KernelizedFeatures(embedding=embk, m=m, s=0.3, lam=1.0, d=d)
+
+	def kfit():
+		kf.fit_gp(xk, yk)
+		return kf.mean_std(xtk)
+	peak0 = torch.cuda.max_memory_allocated()
+	torch.cuda.reset_peak_memory_stats()
+	t, (muk, sdk) = timed(kfit, reps=3)
+	peak = torch.cuda.max_memory_allocated()
+	# parity on a sub-problem the oracle finishes in seconds: the same features, 8192 rows, against the one-shot normal equations
+	ns = 8192
+	Wk = embk.W.double().cpu().numpy()
+	Q = O.rff_embed(xk[:ns].double().cpu().numpy(), Wk, m)
+	_, invV, theta = O.kernelized_features_fit(Q, yk[:ns].double().cpu().numpy(), 0.3, 1.0)
+	mu_o, sd_o = O.kernelized_features_mean_std(O.rff_embed(xtk[:256].double().cpu().numpy(), Wk, m), invV, theta, 0.3)
+	kf2 = KernelizedFeatures(embedding=embk, m=m, s=0.3, lam=1.0, d=d)
+	kf2.slab_bytes = m * 4 * 3072          # three slabs
+	kf2.fit_gp(xk[:ns], yk[:ns])
+	mu2, sd2 = kf2.mean_std(xtk[:256])
+	relk = lambda a, b: float(np.linalg.norm(a.double().cpu().numpy() - b) / np.linalg.norm(b))
+	Fk = float(n) * m * m + m ** 3 / 3.0 + float(M) * m * m + 2.0 * n * d * m
+	out["KF"] = {"workload": "KernelizedFeatures.fit_gp + mean_std on RFF features: N=262144 d=64 m=8192 fp32, M=4096, Phi streamed in <= 2 GiB row slabs",
+				 "seconds": round(t, 4), "bound": "mfma", "achieved": round(Fk / t / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+				 "frac": round(Fk / t / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+				 "algorithmic_flop": "N m^2 (lower-triangular Phi^T Phi) + m^3/3 + M m^2 + 2 N d m (embed) = %.3e" % Fk,
+				 "peak_device_bytes": int(peak), "phi_bytes_if_materialised": int(n) * m * 4,
+				 "parity": {"sub_problem": "N=8192 (three slabs) vs the oracle's one-shot normal equations, 256 test points",
+							"mu": float("%.2e" % relk(mu2, mu_o)), "sigma": float("%.2e" % relk(sd2, sd_o)), "tolerance": 2e-3}}
+	del kf, kf2, xk, yk
+	torch.cuda.empty_cache()
 	return out
 
 

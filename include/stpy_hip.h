@@ -175,7 +175,8 @@ int stpy_combine(int dtype, int64_t m, int64_t n, void* out, int64_t ldo, const 
 int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const void* z,
                      void* out2, void* stream);
 
-/* C (op) A B^T with A: m x k, B: n x k, C: m x n.  mode 0: C = A B^T, 1: C -= A B^T.
+/* C (op) A B^T with A: m x k, B: n x k, C: m x n.  mode 0: C = A B^T, 1: C -= A B^T, 2: C += A B^T (slab-wise accumulation
+ * of Phi^T Phi in the feature-space normal equations, kernelized_features.py:236-240).
  * lower_only: skip 128x128 tiles strictly above the diagonal (m == n).  This is the MFMA
  * contraction under potrf / trsm; exported for the roofline bench and the full-covariance
  * branch gauss_procc.py:396-399. */

@@ -7,8 +7,11 @@ Ridge regression on a finite feature map Phi (n x m), e.g. random Fourier featur
     V = Phi^T Phi + s^2 lam I,   theta = V^-1 Phi^T y,   mean = Phi* theta,
     std = s sqrt(diag(Phi* V^-1 Phi*^T)).
 Device mapping -- every contraction is the NT MFMA GEMM because the embedding is produced
-TRANSPOSED (Phi^T, m x n: ``embed_t``):
-    V           stpy_gemm_nt(Phi^T, Phi^T)  lower triangle  (+ s^2 lam on the diagonal)
+TRANSPOSED (Phi^T, m x n: ``embed_t``), and Phi is STREAMED: row slabs of x are embedded one at a time (``slab_bytes`` of
+features live, 2 GB by default) and accumulated, so the n x m feature matrix is never materialised (SURVEY.md section 8f
+rank 2: at BASELINE config 5's shape it would be 34 GB):
+    V          += Phi_slab^T Phi_slab   stpy_gemm_nt(Phi_slab^T, Phi_slab^T, mode "+=")  lower triangle, then + s^2 lam on the diagonal
+    Phi^T y    += Phi_slab^T y_slab     stpy_predict (row sums against y_slab) + stpy_combine(ADD)
     V = L L^T   stpy_potrf          (the reference takes pinverse(V); V is SPD for s, lam > 0)
     Phi^T y     stpy_predict (row sums against y),   theta: stpy_trsv forward + backward
     X = Phi* L^-T      stpy_trsm_right_lt,   mean = X (L^-1 Phi^T y),  std = s sqrt(rowsum(X o X))
@@ -55,6 +58,7 @@ class KernelizedFeatures:
 		self.beta_fun = beta_fun
 		self.bound = bound
 		self.nb = 0
+		self.slab_bytes = 2 << 30          # features held at a time while V and Phi^T y are accumulated (fit_gp)
 		self._L = self._winv = self._u = self._theta = None
 
 	# ------------------------------------------------------------------ small API mirrors
@@ -107,7 +111,7 @@ class KernelizedFeatures:
 		self.fit_gp(self.x if x is None else x, self.y if y is None else y)
 
 	def fit_gp(self, x, y):
-		"""kernelized_features.py:118-138 + :236-240."""
+		"""kernelized_features.py:118-138 + :236-240, streaming over row slabs of x (see the module header)."""
 		lib = _lib.load()
 		self.x, self.y = x, y
 		self.n = list(x.size())[0]
@@ -115,13 +119,40 @@ class KernelizedFeatures:
 		self.data = True
 		xd = _lib.to_device(x)
 		yd = _lib.to_device(y, xd.dtype).reshape(-1)
-		PhiT = _lib.to_device(self._embed_t(xd), xd.dtype)            # (m, n)
-		m, n = PhiT.shape
-		dt = _lib.dtype_code(PhiT.dtype)
+		n = xd.shape[0]
+		esz = xd.element_size()
 		st = _lib.stream_ptr
-		V = torch.empty((m, m), dtype=PhiT.dtype, device=PhiT.device)
-		_lib.check(lib.stpy_gemm_nt(dt, m, m, n, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(V), V.stride(0), 0, 1, st()), "stpy_gemm_nt")
-		V.diagonal().add_(float(self.s) ** 2 * float(self.lam))
+		dt = _lib.dtype_code(xd.dtype)
+		V = rhs = part = None
+		m = None
+		r0 = 0
+		rows = n          # slab height: set once the feature count is known (first slab: a probe of at most 4096 rows)
+		first = True
+		while r0 < n:
+			take = min(4096 if first and m is None else rows, n - r0)
+			PhiT = _lib.to_device(self._embed_t(xd[r0:r0 + take]), xd.dtype)            # (m, take)
+			if PhiT.stride(1) != 1:
+				PhiT = PhiT.contiguous()
+			if m is None:
+				m = PhiT.shape[0]
+				rows = max(128, (int(self.slab_bytes) // (m * esz)) // 128 * 128)
+				V = torch.empty((m, m), dtype=xd.dtype, device=xd.device)
+				rhs = torch.empty((1, m), dtype=xd.dtype, device=xd.device)
+				part = torch.empty((1, m), dtype=xd.dtype, device=xd.device)
+			# V (+)= Phi_slab^T Phi_slab, lower tiles only: mode 0 for the first slab, 2 (accumulate) afterwards
+			_lib.check(lib.stpy_gemm_nt(dt, m, m, take, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(V), V.stride(0),
+										0 if first else 2, 1, st()), "stpy_gemm_nt")
+			# Phi_slab^T y_slab: row sums of Phi^T against y
+			ys = yd[r0:r0 + take]
+			tgt = rhs if first else part
+			_lib.check(lib.stpy_predict(dt, m, take, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(ys), None, _lib.ptr(tgt), None, 0, st()), "stpy_predict")
+			if not first:
+				_lib.check(lib.stpy_combine(dt, 1, m, _lib.ptr(rhs), m, _lib.ptr(part), m, _lib.OUT_ADD, 0.0, st()), "stpy_combine")
+			first = False
+			r0 += take
+			del PhiT
+		# + s^2 lam on the diagonal (an in-place pass of the elementwise kernel: out = out, then the diagonal term)
+		_lib.check(lib.stpy_combine(dt, m, m, _lib.ptr(V), V.stride(0), _lib.ptr(V), V.stride(0), _lib.OUT_SET, float(self.s) ** 2 * float(self.lam), st()), "stpy_combine")
 		self._Vlow = V.clone()                                         # lower triangle of V, for the ``V`` property
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(m)),), dtype=V.dtype, device=V.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, m, self.nb)),), dtype=torch.uint8, device=V.device)
@@ -130,9 +161,8 @@ class KernelizedFeatures:
 		bad = int(info.item())
 		if bad != 0:
 			raise torch.linalg.LinAlgError("KernelizedFeatures: Phi^T Phi + s^2 lam I is not positive definite (leading minor %d)" % bad)
-		# rhs = Phi^T y (row sums of Phi^T against y), u = L^-1 rhs, theta = L^-T u
-		rhs = torch.empty((m,), dtype=V.dtype, device=V.device)
-		_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(yd), None, _lib.ptr(rhs), None, 0, st()), "stpy_predict")
+		# u = L^-1 (Phi^T y), theta = L^-T u
+		rhs = rhs.reshape(-1)
 		u = torch.empty_like(rhs)
 		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(rhs), _lib.ptr(u), 0, st()), "stpy_trsv")
 		scratch = u.clone()
@@ -198,7 +228,9 @@ class KernelizedFeatures:
 		_lib.check(lib.stpy_trsm_right_lt(dt, M, m, _lib.ptr(L), L.stride(0), _lib.ptr(self._winv), self._winv.numel(), _lib.ptr(X), X.stride(0), self.nb, 0, None, 0, st()), "stpy_trsm_right_lt")
 		mu, ss = torch.empty((M,), dtype=L.dtype, device=L.device), torch.empty((M,), dtype=L.dtype, device=L.device)
 		_lib.check(lib.stpy_predict(dt, M, m, _lib.ptr(X), X.stride(0), _lib.ptr(self._u), None, _lib.ptr(mu), _lib.ptr(ss), 2, st()), "stpy_predict")
-		std = float(self.s) * torch.sqrt(ss)
+		# std = s sqrt(ss) = sqrt(0 - (-s^2) ss): the prediction epilogue with a zero prior term (no torch arithmetic on the vectors)
+		std = torch.empty_like(ss)
+		_lib.check(lib.stpy_predict_finish(dt, M, None, _lib.ptr(ss), _lib.ptr(torch.zeros_like(ss)), -float(self.s) ** 2, _lib.ptr(std), 0, st()), "stpy_predict_finish")
 		return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(std.reshape(-1, 1), xtest))
 
 	mean_var = mean_std

@@ -271,6 +271,8 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int6
 	if (m <= 0 || n <= 0) return 0;
 	if (!A || !B || !C) { set_error("stpy_gemm_nt: null pointer"); return -5; }
 	if (k < 0 || lda < k || ldb < k || ldc < n) { set_error("stpy_gemm_nt: leading dimensions lda=%lld ldb=%lld (k=%lld) ldc=%lld (n=%lld)", (long long)lda, (long long)ldb, (long long)k, (long long)ldc, (long long)n); return -6; }
+	if (mode < 0 || mode > 2) { set_error("stpy_gemm_nt: mode %d (0: C = A B^T, 1: C -= A B^T, 2: C += A B^T)", mode); return -11; }
+	if (mode == 2) mode = 5;          // (internal numbering: 2-4 are the fused-epilogue forms)
 	hipStream_t st = (hipStream_t)stream;
 	ProfScope ps(TAG_GEMM_API, (lower_only && m == n) ? (double)m * (double)n * (double)k : 2.0 * (double)m * (double)n * (double)k, st);
 	DISPATCH(dtype,

@@ -188,10 +188,12 @@ template <typename T, int KIND> __device__ __forceinline__ T gram_dfactor(T acc,
 // 4 evidence-gradient weight): the heavy epilogues must not share an instantiation with the plain
 // contraction -- their code raises register pressure enough to push the accumulators of the whole
 // kernel into scratch.
-template <typename T, bool GUARD, bool SUB, int EPI>
+// ACC: 0 overwrite (C = ...), 1 subtract (C -= A B^T), 2 add (C += A B^T: the slab-wise accumulation of Phi^T Phi)
+template <typename T, bool GUARD, int ACC, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_nt_kernel(GemmArgs<T> p)
 {
+	constexpr bool SUB = ACC == 1, LOADC = ACC != 0;
 	typedef Mfma<T> MM;
 	typedef typename MM::v4 v4;
 	typedef typename MM::v2 v2;
@@ -390,7 +392,7 @@ void gemm_nt_kernel(GemmArgs<T> p)
 #pragma unroll
 			for (int tn = 0; tn < 4; ++tn) {
 				T v = (EPI == 3) ? gram_ha[tn] + gram_hb : T(0);
-				if (SUB) {      // unconditional loads (clamped address when ragged): no per-element branches
+				if (LOADC) {      // unconditional loads (clamped address when ragged): no per-element branches
 					if (!GUARD) v = crow[tn * 16];
 					else v = ctile[(unsigned)lr_c * ldc32 + (unsigned)min(wn * 64 + r16 + tn * 16, p.n - 1 - col0)];
 				}
@@ -685,10 +687,11 @@ void gemm_nt_kernel(GemmArgs<T> p)
 // a "+v" operand, which keeps the MFMAs that read it behind the wait.
 // Measured (tools/dtv_probe.hip, the stand-alone prototype): K-loop slope 73.3 TFLOP/s against 69.1.
 // ------------------------------------------------------------------------------------------
-template <typename T, bool SUB>
+template <typename T, int ACC>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_nt_dtv_kernel(GemmArgs<T> p)
 {
+	constexpr bool SUB = ACC == 1, LOADC = ACC != 0;          // ACC as in gemm_nt_kernel: 0 overwrite, 1 subtract, 2 add
 	typedef Mfma<T> MM;
 	typedef typename MM::v4 v4;
 	constexpr int CH = 16 / sizeof(T);                 // elements per 16-byte chunk (2 doubles / 4 floats): one MFMA k-step each
@@ -821,7 +824,7 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 		for (int i = 0; i < 4; ++i) {
 			const T* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + MM::crow(lane, i)) * ldc32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
-			for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = SUB ? crow[tn * 16] : T(0);
+			for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = LOADC ? crow[tn * 16] : T(0);
 		}
 	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
 	if constexpr (SUB && !MM::HAS_NEG) {         // f32 has no negating MFMA: accumulate A B^T - C and flip the sign once at the store
@@ -1156,7 +1159,7 @@ void splitk_reduce_kernel(const T* __restrict__ work, int splits, int64_t m, int
 	T sum = T(0);
 	for (int s = 0; s < splits; ++s) sum += work[(int64_t)s * m * n + e];
 	T* c = C + (e / n) * ldc + (e % n);
-	*c = mode == 1 ? *c - sum : sum;
+	*c = mode == 1 ? *c - sum : (mode == 5 ? *c + sum : sum);
 }
 
 // ---- skinny product: m <= SKINNY_MAX rows of A against all n rows of B (a handful of right-hand
@@ -1205,7 +1208,7 @@ void gemm_skinny_kernel(int m, int64_t k, const T* __restrict__ A, int64_t lda, 
 	if (tid < m) {
 		const T sum = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 		T* c = C + (int64_t)tid * ldc + j;
-		*c = mode == 1 ? *c - sum : sum;
+		*c = mode == 1 ? *c - sum : (mode == 5 ? *c + sum : sum);
 	}
 }
 
@@ -1236,7 +1239,8 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		if (mode == 0) { set_error("gemm_nt: k == 0 with overwrite mode is not supported"); return -4; }
 		return 0;
 	}
-	const bool plain = (mode == 0 || mode == 1) && !lower_only && !bc && !C2;
+	// mode 5: C += A B^T (public mode 2 of stpy_gemm_nt) -- the tile kernels with the C tile loaded into the accumulators
+	const bool plain = (mode == 0 || mode == 1 || mode == 5) && !lower_only && !bc && !C2;
 	// (the block solve multiplies a row block by an inverse diagonal block IN PLACE, C == A: fine for the
 	// tile kernel, whose single column of tiles reads its rows of A before storing, not for a kernel
 	// that finishes one column of C at a time)
@@ -1367,9 +1371,10 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	}
 	{
 		const int64_t dtv_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n * p.ksplit;
-		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1) && !g_gemm_exp && lda < (1 << 24) && ldb < (1 << 24) && k >= g_gemm_dtv_min_k * (int)(8 / sizeof(T))) {
-			if (mode == 1 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, true>), grid, block, 0, st, p);
-			else hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, false>), grid, block, 0, st, p);
+		if (g_gemm_dtv > 0 && dtv_tiles >= g_gemm_dtv && aligned && (mode == 0 || mode == 1 || mode == 5) && !g_gemm_exp && lda < (1 << 24) && ldb < (1 << 24) && k >= g_gemm_dtv_min_k * (int)(8 / sizeof(T))) {
+			if (mode == 1 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, 1>), grid, block, 0, st, p);
+			else if (mode == 5 && p.ksplit == 1) hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, 2>), grid, block, 0, st, p);
+			else hipLaunchKernelGGL((gemm_nt_dtv_kernel<T, 0>), grid, block, 0, st, p);
 			if (p.ksplit > 1) {
 				const int64_t total = m * n;
 				hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -1379,17 +1384,18 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		}
 	}
 	if (p.ksplit > 1) {
-		if (aligned) STPY_LAUNCH(false, false, 0); else STPY_LAUNCH(true, false, 0);
+		if (aligned) STPY_LAUNCH(false, 0, 0); else STPY_LAUNCH(true, 0, 0);
 		const int64_t total = m * n;
 		hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
 		                   (const T*)split_work, p.ksplit, m, n, C, ldc, mode);
 	}
-	else if (mode == 1) { if (aligned) STPY_LAUNCH(false, true, 0); else STPY_LAUNCH(true, true, 0); }
-	else if (mode == 0) { if (aligned) STPY_LAUNCH(false, false, 0); else STPY_LAUNCH(true, false, 0); }
-	else if (mode == 3) { if (aligned) STPY_LAUNCH(false, false, 3); else STPY_LAUNCH(true, false, 3); }
-	else if (mode == 4) { if (aligned) STPY_LAUNCH(false, false, 4); else STPY_LAUNCH(true, false, 4); }
+	else if (mode == 1) { if (aligned) STPY_LAUNCH(false, 1, 0); else STPY_LAUNCH(true, 1, 0); }
+	else if (mode == 5) { if (aligned) STPY_LAUNCH(false, 2, 0); else STPY_LAUNCH(true, 2, 0); }
+	else if (mode == 0) { if (aligned) STPY_LAUNCH(false, 0, 0); else STPY_LAUNCH(true, 0, 0); }
+	else if (mode == 3) { if (aligned) STPY_LAUNCH(false, 0, 3); else STPY_LAUNCH(true, 0, 3); }
+	else if (mode == 4) { if (aligned) STPY_LAUNCH(false, 0, 4); else STPY_LAUNCH(true, 0, 4); }
 	else if (mode == 2) {
-		if constexpr (sizeof(T) == 4) { if (aligned) STPY_LAUNCH(false, false, 2); else STPY_LAUNCH(true, false, 2); }
+		if constexpr (sizeof(T) == 4) { if (aligned) STPY_LAUNCH(false, 0, 2); else STPY_LAUNCH(true, 0, 2); }
 	}
 	else { set_error("gemm_nt: unknown mode %d", mode); return -11; }
 #undef STPY_LAUNCH

@@ -665,7 +665,7 @@ void trsv_flow_kernel(const T* __restrict__ L, int64_t ldl, const T* __restrict_
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores ...
 	__syncthreads();                                           // ... before ONE lane publishes the counter
 #if STPY_LAB
-	if (k == fault_ticket) return;          // test hook (stpy_tune key 22): this block is never published -> its successor's wait must time out
+	if (k + 1 == fault_ticket) return;      // test hook (stpy_tune key 22 = ticket + 1; 0 = off): this block is never published -> its successor's wait must time out
 #endif
 	if (tid == 0) store_sc1(&sy->count, (unsigned)(k + 1));
 }
@@ -735,35 +735,65 @@ int trsv(int64_t n, const T* L, int64_t ldl, const T* winv, T* y, T* out, int tr
 }
 
 // ------------------------------------------------------------------------------------------
-// Prediction epilogue: one workgroup per test point streams its row of X = K* L^-T once.
+// Prediction epilogue: X = K* L^-T is streamed ONCE (M * N * w bytes: HBM-bound), mu and the variance term come out of the
+// same pass.  A workgroup owns PR_ROWS consecutive test points: every 16-byte chunk of z it loads is used against all of their
+// rows (one workgroup per row re-read the whole of z from L2 for every row -- as many bytes again as X itself through the
+// L1/L2 path), and each lane keeps PR_ROWS + 1 sixteen-byte loads per step in flight, two steps unrolled.
 // ------------------------------------------------------------------------------------------
-template <typename T>
+constexpr int PR_ROWS = 4;
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256)
-void predict_kernel(const T* __restrict__ X, int64_t ldx, int n, const T* __restrict__ z,
+void predict_kernel(const T* __restrict__ X, int64_t ldx, int m, int n, const T* __restrict__ z,
                     const T* __restrict__ kdiag, T* __restrict__ mu, T* __restrict__ sigma, int clamp)
 {
-	const int64_t i = blockIdx.x;
-	const T* xr = X + i * ldx;
-	T s1 = T(0), s2 = T(0);
-	for (int k = threadIdx.x; k < n; k += 256) {
-		const T v = xr[k];
-		s1 += v * z[k];
-		s2 += v * v;
-	}
-	__shared__ T r1[4], r2[4];
+	constexpr int CH = 16 / (int)sizeof(T);
+	typedef T vch __attribute__((ext_vector_type(CH)));
+	const int row0 = blockIdx.x * PR_ROWS;
+	const T* xr[PR_ROWS];
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-	if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+	for (int r = 0; r < PR_ROWS; ++r) xr[r] = X + (int64_t)min(row0 + r, m - 1) * ldx;          // (rows past the end re-read the last one; not stored)
+	T s1[PR_ROWS], s2[PR_ROWS];
+#pragma unroll
+	for (int r = 0; r < PR_ROWS; ++r) s1[r] = s2[r] = T(0);
+	if (VEC) {
+		const int nch = n / CH;
+#pragma unroll 2
+		for (int c = threadIdx.x; c < nch; c += 256) {
+			const vch zv = *(const vch*)(z + (int64_t)c * CH);
+			vch xv[PR_ROWS];
+#pragma unroll
+			for (int r = 0; r < PR_ROWS; ++r) xv[r] = __builtin_nontemporal_load((const vch*)(xr[r] + (int64_t)c * CH));          // read once: keep z in the caches instead
+#pragma unroll
+			for (int r = 0; r < PR_ROWS; ++r)
+#pragma unroll
+				for (int e = 0; e < CH; ++e) { s1[r] += xv[r][e] * zv[e]; s2[r] += xv[r][e] * xv[r][e]; }
+		}
+	} else {
+		for (int k = threadIdx.x; k < n; k += 256) {
+			const T zk = z[k];
+#pragma unroll
+			for (int r = 0; r < PR_ROWS; ++r) { const T v = xr[r][k]; s1[r] += v * zk; s2[r] += v * v; }
+		}
+	}
+	__shared__ T r1[PR_ROWS][4], r2[PR_ROWS][4];
+#pragma unroll
+	for (int r = 0; r < PR_ROWS; ++r) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { s1[r] += __shfl_xor(s1[r], o); s2[r] += __shfl_xor(s2[r], o); }
+		if ((threadIdx.x & 63) == 0) { r1[r][threadIdx.x >> 6] = s1[r]; r2[r][threadIdx.x >> 6] = s2[r]; }
+	}
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		s1 = r1[0] + r1[1] + r1[2] + r1[3];
-		s2 = r2[0] + r2[1] + r2[2] + r2[3];
-		if (mu) mu[i] = s1;
+	if (threadIdx.x < PR_ROWS && row0 + (int)threadIdx.x < m) {
+		const int r = threadIdx.x;
+		const int64_t i = row0 + r;
+		const T a = r1[r][0] + r1[r][1] + r1[r][2] + r1[r][3];
+		const T b = r2[r][0] + r2[r][1] + r2[r][2] + r2[r][3];
+		if (mu) mu[i] = a;
 		if (sigma) {
 			if (clamp == 2) {           // raw partial sum of squares (multi-GPU: reduced across ranks first)
-				sigma[i] = s2;
+				sigma[i] = b;
 			} else {
-				T var = kdiag[i] - s2;
+				T var = kdiag[i] - b;
 				if (clamp && var < T(0)) var = T(0);
 				sigma[i] = sqrt(var);
 			}
@@ -776,7 +806,11 @@ int predict(int64_t m, int64_t n, const T* X, int64_t ldx, const T* z, const T* 
 {
 	if (m <= 0) return 0;
 	if (n > INT32_MAX || m > INT32_MAX) { set_error("predict: dimension exceeds int32"); return -2; }
-	hipLaunchKernelGGL((predict_kernel<T>), dim3((unsigned)m), dim3(256), 0, st, X, ldx, (int)n, z, kdiag, mu, sigma, clamp);
+	constexpr int CH = 16 / (int)sizeof(T);
+	const bool vec = n > 0 && n % CH == 0 && ldx % CH == 0 && ((((uintptr_t)X | (uintptr_t)z) & 15) == 0);
+	const dim3 grid((unsigned)((m + PR_ROWS - 1) / PR_ROWS));
+	if (vec) hipLaunchKernelGGL((predict_kernel<T, true>), grid, dim3(256), 0, st, X, ldx, (int)m, (int)n, z, kdiag, mu, sigma, clamp);
+	else hipLaunchKernelGGL((predict_kernel<T, false>), grid, dim3(256), 0, st, X, ldx, (int)m, (int)n, z, kdiag, mu, sigma, clamp);
 	return check_launch("predict");
 }
 

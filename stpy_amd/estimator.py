@@ -82,16 +82,21 @@ class Estimator(ABC):
 		dims = np.cumsum([0] + [sl[5] for sl in slots]).astype(int)
 		dim = int(dims[-1])
 
+		# The search works on a COPY of the stored parameters (one shallow copy per kernel item): trial points -- slices of a
+		# tensor that requires grad -- never land in kernel_object.params_dict, so an exception in the middle of the search (a
+		# trial point that is not positive definite, a keyboard interrupt) leaves the object exactly as it was.  Only the noise
+		# level has to live on the object while a value is computed (log_marginal reads self.s); it is restored in `finally`.
+		trial_dict = {k: dict(v) for k, v in self.kernel_object.params_dict.items()}
+
 		def build_input(xt):
 			"""x (flat tensor) -> the override dictionary log_marginal takes; the noise goes to self.s"""
-			input_dict = self.kernel_object.params_dict
 			for c, (key, var, _, _, _, _) in enumerate(slots):
 				piece = xt[dims[c]:dims[c + 1]]
 				if key != "likelihood":
-					input_dict[key][var] = piece
+					trial_dict[key][var] = piece
 				else:
 					self.s = piece
-			return input_dict
+			return trial_dict
 
 		def cost(xt):
 			f = self.log_marginal(self.kernel_object, build_input(xt), weight)
@@ -101,7 +106,11 @@ class Estimator(ABC):
 
 		def fun(xnp):
 			xt = torch.tensor(np.asarray(xnp, dtype=np.float64).reshape(-1), dtype=torch.float64, requires_grad=True)
-			f = cost(xt)
+			try:
+				f = cost(xt)
+			except torch.linalg.LinAlgError:
+				# a trial point whose matrix is not positive definite: +inf, zero slope -- every line search backs off from it
+				return float("inf"), np.zeros(xt.numel())
 			f.backward()
 			return float(f.detach().reshape(-1)[0]), xt.grad.detach().numpy().astype(np.float64).reshape(-1)
 
@@ -118,87 +127,87 @@ class Estimator(ABC):
 
 		s_backup = self.s
 		objective_values, objective_params = [], []
-		if optimizer == "pytorch-minimize":
-			bounds = slots[0][4]
-			try:
-				from torchmin import minimize as minimize_torch          # the reference's solver when it is installed
-			except Exception:                                            # noqa: BLE001
-				minimize_torch = None
-			import scipy.optimize
-			for rep in range(restarts):
-				x_init = initial_point()
-				if minimize_torch is not None and bounds is None:
-					res = minimize_torch(cost, torch.from_numpy(x_init), method='l-bfgs', tol=1e-10, disp=verbose + 1, options={'max_iter': maxiter, 'gtol': mingradnorm})
-					objective_params.append(np.asarray(res.x.detach().numpy(), dtype=np.float64))
-					objective_values.append(float(res.fun))
-				else:
-					res = scipy.optimize.minimize(fun, x_init, jac=True, method='L-BFGS-B', bounds=bounds,
-												  options={'maxiter': maxiter, 'gtol': mingradnorm, 'ftol': 1e-12})
-					objective_params.append(np.asarray(res.x, dtype=np.float64))
-					objective_values.append(float(res.fun))
-				if verbose:
-					print("restart", rep, "f =", objective_values[-1], "x =", objective_params[-1])
-		elif optimizer == "pymanopt":
-			for rep in range(restarts):
-				x = initial_point() if any(sl[2] is not None for sl in slots) else np.concatenate([np.asarray(sl[3].random_point(), dtype=np.float64).reshape(-1) * scale for sl in slots])
-				f, g = fun(x)
-				step = 1.0 / max(np.linalg.norm(g), 1e-12)
-				for it in range(maxiter):
-					gn = np.linalg.norm(g)
-					if gn < mingradnorm:
-						break
-					# backtracking (Armijo) line search along -g, the step grown again after a success
-					t = step
-					while True:
-						xn = x - t * g
-						try:
-							fn, gnew = fun(xn)
-						except torch.linalg.LinAlgError:
-							fn = np.inf
-						if fn <= f - 1e-4 * t * gn * gn or t < 1e-14:
-							break
-						t *= 0.5
-					if not np.isfinite(fn) or t < 1e-14:
-						break
-					x, f, g, step = xn, fn, gnew, 2.0 * t
-				objective_params.append(x)
-				objective_values.append(f)
-				if verbose:
-					print("restart", rep, "f =", f, "x =", x, "iterations", it)
-		elif optimizer == "bisection":
-			if dim != 1 or slots[0][4] is None:
-				raise ValueError("bisection: exactly one scalar variable with bounds (a, b)")
-			a, b = [float(v) for v in slots[0][4]]
-			memo = {}
-
-			def g(v):
-				if v not in memo:
-					memo[v] = float(cost(torch.tensor([v], dtype=torch.float64)).detach().reshape(-1)[0])
-				return memo[v]
-			if g(a) < 0.:
-				root = a
-			elif g(a) * g(b) > 0.:
-				raise ValueError("Bisection method fails.")          # (the reference prints this and returns None)
-			else:
-				lo, hi = a, b
-				root = None
-				for _ in range(100):
-					mid = (lo + hi) / 2.
-					if g(lo) * g(mid) < 0:
-						hi = mid
-					elif g(hi) * g(mid) < 0:
-						lo = mid
+		try:
+			if optimizer == "pytorch-minimize":
+				bounds = slots[0][4]
+				try:
+					from torchmin import minimize as minimize_torch          # the reference's solver when it is installed
+				except Exception:                                            # noqa: BLE001
+					minimize_torch = None
+				import scipy.optimize
+				for rep in range(restarts):
+					x_init = initial_point()
+					if minimize_torch is not None and bounds is None:
+						res = minimize_torch(cost, torch.from_numpy(x_init), method='l-bfgs', tol=1e-10, disp=verbose + 1, options={'max_iter': maxiter, 'gtol': mingradnorm})
+						objective_params.append(np.asarray(res.x.detach().numpy(), dtype=np.float64))
+						objective_values.append(float(res.fun))
 					else:
-						root = mid if g(mid) == 0 else lo
-						break
-				if root is None:
-					root = (lo + hi) / 2.
-			objective_params.append(np.array([root]))
-			objective_values.append(g(root))
-		elif optimizer in ("scipy", "discrete"):
-			raise NotImplementedError("optimizer='%s' does not run in the reference snapshot either (estimator.py:124-126, :227-229)" % optimizer)
-		else:
-			raise AssertionError("Optimizer not implemented.")          # estimator.py:231
+						res = scipy.optimize.minimize(fun, x_init, jac=True, method='L-BFGS-B', bounds=bounds,
+													  options={'maxiter': maxiter, 'gtol': mingradnorm, 'ftol': 1e-12})
+						objective_params.append(np.asarray(res.x, dtype=np.float64))
+						objective_values.append(float(res.fun))
+					if verbose:
+						print("restart", rep, "f =", objective_values[-1], "x =", objective_params[-1])
+			elif optimizer == "pymanopt":
+				for rep in range(restarts):
+					x = initial_point() if any(sl[2] is not None for sl in slots) else np.concatenate([np.asarray(sl[3].random_point(), dtype=np.float64).reshape(-1) * scale for sl in slots])
+					f, g = fun(x)
+					step = 1.0 / max(np.linalg.norm(g), 1e-12)
+					for it in range(maxiter):
+						gn = np.linalg.norm(g)
+						if gn < mingradnorm:
+							break
+						# backtracking (Armijo) line search along -g, the step grown again after a success
+						t = step
+						while True:
+							xn = x - t * g
+							fn, gnew = fun(xn)
+							if fn <= f - 1e-4 * t * gn * gn or t < 1e-14:
+								break
+							t *= 0.5
+						if not np.isfinite(fn) or t < 1e-14:
+							break
+						x, f, g, step = xn, fn, gnew, 2.0 * t
+					objective_params.append(x)
+					objective_values.append(f)
+					if verbose:
+						print("restart", rep, "f =", f, "x =", x, "iterations", it)
+			elif optimizer == "bisection":
+				if dim != 1 or slots[0][4] is None:
+					raise ValueError("bisection: exactly one scalar variable with bounds (a, b)")
+				a, b = [float(v) for v in slots[0][4]]
+				memo = {}
+
+				def g(v):
+					if v not in memo:
+						memo[v] = float(cost(torch.tensor([v], dtype=torch.float64)).detach().reshape(-1)[0])
+					return memo[v]
+				if g(a) < 0.:
+					root = a
+				elif g(a) * g(b) > 0.:
+					raise ValueError("Bisection method fails.")          # (the reference prints this and returns None)
+				else:
+					lo, hi = a, b
+					root = None
+					for _ in range(100):
+						mid = (lo + hi) / 2.
+						if g(lo) * g(mid) < 0:
+							hi = mid
+						elif g(hi) * g(mid) < 0:
+							lo = mid
+						else:
+							root = mid if g(mid) == 0 else lo
+							break
+					if root is None:
+						root = (lo + hi) / 2.
+				objective_params.append(np.array([root]))
+				objective_values.append(g(root))
+			elif optimizer in ("scipy", "discrete"):
+				raise NotImplementedError("optimizer='%s' does not run in the reference snapshot either (estimator.py:124-126, :227-229)" % optimizer)
+			else:
+				raise AssertionError("Optimizer not implemented.")          # estimator.py:231
+		finally:
+			self.s = s_backup          # whatever happened inside the search, no trial value stays on the object
 
 		if save:
 			with open(save_name, 'wb') as fh:

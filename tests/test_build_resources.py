@@ -154,7 +154,7 @@ def test_dtv_kernel_fragments_are_not_copied(tmp_path):
 	subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-S", "--cuda-device-only",
 					os.path.join(CSRC, "gemm.hip"), "-o", str(asm)], capture_output=True, text=True, check=True)
 	src = asm.read_text()
-	names = [n for n in re.findall(r"^(_ZN4stpy18gemm_nt_dtv_kernel\w+):", src, re.M) if "Lb1EEEv" in n]
+	names = [n for n in re.findall(r"^(_ZN4stpy18gemm_nt_dtv_kernel\w+):", src, re.M) if "Li1EEEv" in n]          # ACC = 1: the subtracting form
 	assert len(names) == 2
 	for name in names:
 		body = src[src.index(name + ":"):].split(".Lfunc_end")[0].split("\n")

@@ -1012,3 +1012,36 @@ def test_estimator_base_and_general_driver(S):
 	assert (fa < 0 and g3 == 0.2) or abs(lml(GP3)) < 1e-6 * max(1.0, abs(fa))
 	with pytest.raises(AssertionError):
 		GP3.optimize_params_general(params={'0': {'gamma': (None, Euclidean(1), None)}}, optimizer="nope")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-3)])
+def test_kernelized_features_streaming_vs_oracle(S, dtype, tol):
+	"""KernelizedFeatures.fit_gp streams Phi in row slabs (kernelized_features.py:228-240 without the n x m matrix): N = 20 000,
+	m = 512 random Fourier features, a slab budget small enough for eight slabs (aligned ones and a ragged last one), against the
+	oracle's one-shot normal equations; and the slab size must not change the result beyond rounding."""
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	rng = np.random.RandomState(77)
+	n, d, m, M = 20000, 6, 512, 300
+	x = rng.uniform(-1, 1, size=(n, d))
+	y = np.sin(x[:, :1] * 2) + x[:, 1:2] * x[:, 2:3] + 0.1 * rng.normal(size=(n, 1))
+	xt = rng.uniform(-1, 1, size=(M, d))
+	W = rng.normal(size=(m, d)) / 1.5
+	s, lam, kappa = 0.3, 1.0, 1.2
+	emb = S.RFFEmbedding(gamma=1.5, m=m, d=d, kappa=kappa)
+	emb.W = torch.from_numpy(W)
+	Q = O.rff_embed(x, W, m, kappa=kappa)
+	V_o, invV, theta = O.kernelized_features_fit(Q, y, s, lam)
+	mu_o, std_o = O.kernelized_features_mean_std(O.rff_embed(xt, W, m, kappa=kappa), invV, theta, s)
+	outs = []
+	for slab in (m * 8 * 2560 if dtype == torch.float64 else m * 4 * 2560, 2 << 30):
+		KF = KernelizedFeatures(embedding=emb, m=m, s=s, lam=lam, d=d)
+		KF.slab_bytes = slab
+		KF.fit_gp(T(x).to(dtype).cuda(), T(y).to(dtype).cuda())
+		mu, std = KF.mean_std(T(xt).to(dtype).cuda())
+		assert mu.dtype == dtype and tuple(mu.shape) == (M, 1)
+		assert rel_err(N(mu), mu_o) < tol and rel_err(N(std), std_o) < tol
+		assert rel_err(N(KF.theta_mean()), theta) < tol * 100
+		if dtype == torch.float64:
+			assert rel_err(N(KF.V), V_o) < 1e-10
+		outs.append((N(mu), N(std)))
+	assert rel_err(outs[0][0], outs[1][0]) < (1e-10 if dtype == torch.float64 else 1e-3)

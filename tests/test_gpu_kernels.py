@@ -34,7 +34,7 @@ def spd(rng, n, d=4, s=0.3):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 384, 128), (300, 200, 70), (1, 130, 5), (513, 129, 257), (1024, 1024, 512)])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_nt(L, m, n, k, mode):
 	rng = np.random.RandomState(m * 7 + n * 3 + k + mode)
 	A, B, C = rng.normal(size=(m, k)), rng.normal(size=(n, k)), rng.normal(size=(m, n))
@@ -42,8 +42,32 @@ def test_gemm_nt(L, m, n, k, mode):
 	lib = L.load()
 	rc = lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr())
 	L.check(rc, "gemm")
-	ref = A @ B.T if mode == 0 else C - A @ B.T
+	ref = A @ B.T if mode == 0 else (C - A @ B.T if mode == 1 else C + A @ B.T)
 	assert rel_err(Cd.cpu().numpy(), ref) < 1e-14 * max(1, k) ** 0.5 * 10
+	assert lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, 3, 0, L.stream_ptr()) == -11          # unknown mode: refused
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-13), (torch.float32, 2e-5)])
+def test_gemm_nt_accumulate_lower(L, dtype, tol):
+	"""mode 2 (C += A B^T) on the lower tiles of a square C, slab after slab: what KernelizedFeatures.fit_gp does with Phi^T Phi.
+	Aligned slabs take the direct-to-VGPR kernel, the ragged last one the guarded tile kernel; the upper tiles are never touched."""
+	lib = L.load()
+	rng = np.random.RandomState(17)
+	m, slabs = 512, (1024, 768, 333)
+	code = L.dtype_code(dtype)
+	npdt = np.float64 if dtype == torch.float64 else np.float32
+	Cd = torch.full((m, m), float("nan"), dtype=dtype, device="cuda:0")
+	ref = np.zeros((m, m))
+	for i, k in enumerate(slabs):
+		A = rng.normal(size=(m, k)).astype(npdt)
+		Ad = dev(A, dtype)
+		L.check(lib.stpy_gemm_nt(code, m, m, k, L.ptr(Ad), k, L.ptr(Ad), k, L.ptr(Cd), m, 0 if i == 0 else 2, 1, L.stream_ptr()), "gemm")
+		ref += A.astype(np.float64) @ A.astype(np.float64).T
+	got = Cd.cpu().numpy().astype(np.float64)
+	tiles = np.arange(m) // 128
+	low = tiles[:, None] >= tiles[None, :]
+	assert rel_err(got[low], ref[low]) < tol
+	assert np.isnan(got[~low]).all()
 
 
 @pytest.mark.parametrize("m,n,k,mode", [(1, 512, 4096, 0), (1, 300, 1001, 1), (2, 128, 640, 0), (3, 257, 96, 1), (5, 64, 2048, 0), (8, 512, 1536, 1)])
@@ -56,6 +80,9 @@ def test_gemm_nt_skinny_rows(L, m, n, k, mode):
 	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr()), "gemm")
 	ref = A @ B.T if mode == 0 else C - A @ B.T
 	assert rel_err(Cd.cpu().numpy(), ref) < 1e-13
+	Cd2 = dev(C)
+	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd2), n, 2, 0, L.stream_ptr()), "gemm")
+	assert rel_err(Cd2.cpu().numpy(), C + A @ B.T) < 1e-13
 
 
 @pytest.mark.parametrize("m,n,k,mode,passes", [(256, 128, 4096, 0, 4), (512, 256, 3000, 1, 3), (130, 100, 2500, 0, 5), (128, 128, 1024, 1, 16)])
@@ -95,6 +122,9 @@ def test_gemm_nt_k128_small_grid(L, m, n, mode):
 	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, 0, L.stream_ptr()), "gemm")
 	ref = A @ B.T if mode == 0 else C - A @ B.T
 	assert rel_err(Cd.cpu().numpy(), ref) < 1e-13
+	Cd2 = dev(C)
+	L.check(lib.stpy_gemm_nt(L.F64, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd2), n, 2, 0, L.stream_ptr()), "gemm")
+	assert rel_err(Cd2.cpu().numpy(), C + A @ B.T) < 1e-13
 	# the same product with the kernel switched off gives the same numbers to rounding
 	lib.stpy_tune(8, 0)
 	try:
@@ -942,7 +972,7 @@ def test_trsv_handoff_timeout_is_loud(L):
 		L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
 		assert lib.stpy_async_status(L.stream_ptr()) == 0 and not torch.isnan(zd).any()
 		pytest.skip("fault injection needs the lab build (STPY_HIP_LIB=lab)")
-	lib.stpy_tune(22, 3)
+	lib.stpy_tune(22, 3 + 1)          # ticket 3 is never published
 	try:
 		yd, zd = dev(y), torch.zeros(n, dtype=torch.float64, device="cuda:0")
 		L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
@@ -951,7 +981,7 @@ def test_trsv_handoff_timeout_is_loud(L):
 		assert not np.isnan(z[:4 * 128]).any() and np.isnan(z[4 * 128:]).all()          # blocks 0..3 solved, block 4 timed out, the rest inherit
 		assert lib.stpy_async_status(L.stream_ptr()) == 0                               # read-and-clear
 	finally:
-		lib.stpy_tune(22, -1)
+		lib.stpy_tune(22, 0)
 	yd, zd = dev(y), torch.empty(n, dtype=torch.float64, device="cuda:0")
 	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
 	assert lib.stpy_async_status(L.stream_ptr()) == 0
