@@ -311,6 +311,8 @@ def parse_args(argv=None):
 	ap.add_argument("--m", type=int, default=0)
 	ap.add_argument("--nb", type=int, default=0)
 	ap.add_argument("--nb-dist", type=int, default=0, help="distribution block of the block-cyclic path (0: the class default for the size)")
+	ap.add_argument("--transport", choices=["collective", "fanout", "auto"], default=os.environ.get("STPY_DIST_TRANSPORT", "collective"),
+					help="panel broadcasts of the block-cyclic path: RCCL broadcast (default) or point-to-point fan-out to every peer")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-extra-configs", action="store_true")
 	args = ap.parse_args(argv)
@@ -474,11 +476,36 @@ def main(args):
 		if dist_path:
 			from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
 			kw = {"nb_dist": args.nb_dist} if args.nb_dist else {}
+			kw["transport"] = args.transport
 			g = DistributedGaussianProcess(gamma=math.sqrt(dd), s=s, kappa=1.0, kernel_name="squared_exponential", d=dd, force_path=force_dist, **kw)
 		else:
 			g = GaussianProcess(gamma=math.sqrt(dd), s=s, kappa=1.0, kernel_name="squared_exponential", d=dd)
 		g.nb = args.nb
 		return g
+
+	# Multi-GPU: before anything is timed, the distributed path is checked on a small problem against the single-GPU class on this
+	# very GPU (every rank holds the replicated result; a wrong collective order or a stale panel shows up here, not as a fast wrong number)
+	selfcheck = None
+	if dist_path:
+		ns, ms = 4096 + 384, 256
+		xs, ys, xts = synth(ns, d, ms, dev, seed=99)
+		g1 = GaussianProcess(gamma=math.sqrt(d), s=s, kappa=1.0, kernel_name="squared_exponential", d=d)
+		g1.fit_gp(xs, ys)
+		mu1, sd1 = g1.mean_std(xts)
+		from stpy_amd.parallel.block_cyclic import DistributedGaussianProcess
+		gd = DistributedGaussianProcess(gamma=math.sqrt(d), s=s, kappa=1.0, kernel_name="squared_exponential", d=d, force_path=force_dist, nb_dist=256, transport=args.transport)
+		gd.fit_gp(xs, ys)
+		mud, sdd = gd.mean_std(xts)
+		err = torch.stack([torch.norm(mud - mu1) / torch.norm(mu1), torch.norm(sdd - sd1) / torch.norm(sd1)])
+		if world > 1:
+			errh = err.cpu() if backend != "nccl" else err
+			torch.distributed.all_reduce(errh, op=torch.distributed.ReduceOp.MAX)
+			err = errh
+		selfcheck = {"n": ns, "m": ms, "nb_dist": 256, "mu_rel_err_vs_single_gpu_class": float("%.2e" % float(err[0])), "sigma_rel_err": float("%.2e" % float(err[1])), "tolerance": 1e-8}
+		if not (float(err[0]) < 1e-8 and float(err[1]) < 1e-8):
+			raise RuntimeError("distributed self-check failed: %s" % json.dumps(selfcheck))
+		del g1, gd, xs, ys, xts
+		torch.cuda.empty_cache()
 
 	x, y, xt = synth(n, d, m, dev)
 	gp = make_gp(d, n)
@@ -516,7 +543,7 @@ def main(args):
 		gathered = [None] * world
 		torch.distributed.all_gather_object(gathered, mine)
 		dist_info = {"rccl_ranks": world if backend == "nccl" else 0, "backend": backend, "grid": "%dx%d" % (gp.Pr, gp.Pc), "nb_dist": gp.NB,
-					 "transport": getattr(gp, "transport", "collective"), "per_rank": gathered}
+					 "transport": getattr(gp, "transport", "collective"), "col_exchange": getattr(gp, "col_exchange", None), "selfcheck": selfcheck, "per_rank": gathered}
 	gp_nb = gp.NB if dist_path else None
 	result_check = {"mu_norm": float(torch.norm(mu)), "std_mean": float(std.mean()), "nan": bool(torch.isnan(std).any())}
 	del gp, mu, std, x, y, xt
@@ -541,10 +568,8 @@ def main(args):
 				  "nb_dist": g4.NB if dist_path else None,
 				  "result_check": {"mu_norm": float(torch.norm(mu4)), "std_mean": float(sd4.mean()), "nan": bool(torch.isnan(sd4).any())}}
 			del g4, x4, y4, xt4, mu4, sd4
-		except Exception as exc:          # noqa: BLE001  (the headline line must survive a failure of the extra workload)
+		except Exception as exc:          # noqa: BLE001  (the headline line must survive a failure of the extra workload: it is measured already)
 			c4 = {"workload": "N=131072 d=32", "seconds": None, "error": "%s: %s" % (type(exc).__name__, exc)}
-			if dist_path:
-				raise
 		torch.cuda.empty_cache()
 
 	if rank == 0:

@@ -872,6 +872,9 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 	auto width = [&](int64_t left) { const int64_t w = adaptive ? potrf_auto_nb(left) : nb; return left < w ? left : w; };
 
 	int64_t wk = width(n);                                          // width of the current panel
+	// (stpy_tune key 24: the FIRST panel has nothing to hide behind -- its n x wk left-looking products and wk / 128 diagonal blocks
+	// run alone on the chip -- so it may be narrower than the panels that follow)
+	if (adaptive && g_potrf_first_nb > 0 && g_potrf_first_nb % IB == 0 && g_potrf_first_nb < wk) wk = g_potrf_first_nb;
 	rc = factor_panel<T>(n, 0, wk, A, lda, winv, Pbuf[0], ldp, info, st, gflags);
 	if (rc) return rc;
 	int cur = 0;

@@ -206,7 +206,7 @@ class DistributedGaussianProcess:
 	which is how its own overhead is measured)."""
 
 	def __init__(self, gamma=1, s=0.001, kappa=1., kernel_name="squared_exponential", nu=1.5, kernel=None, d=1,
-				 grid=None, nb_dist=None, ops=None, group=None, force_path=False, transport="auto", col_exchange="allgather", audit=False):
+				 grid=None, nb_dist=None, ops=None, group=None, force_path=False, transport="collective", col_exchange="allgather", audit=False):
 		self.s = s
 		self.d = d
 		self.kernel_object = kernel if kernel is not None else KernelFunction(kernel_name=kernel_name, gamma=gamma, nu=nu, kappa=kappa, d=d)
@@ -283,7 +283,9 @@ class DistributedGaussianProcess:
 		# Transport of the panel broadcasts.  xGMI is point to point (every GPU pair has its own link), so a root that sends its
 		# panel to each peer separately -- one batched group of isend / irecv, which RCCL runs concurrently -- keeps 1 ... P-1 links
 		# busy at once where a ring broadcast is bound by one link per hop.  "auto" takes the fan-out only on RCCL and only when
-		# every visible device pair has peer access; gloo (CPU tests, one-GPU rehearsal) keeps broadcasts unless asked.
+		# every visible device pair has peer access.  The DEFAULT is the plain RCCL broadcast ("collective"): neither form has
+		# run between real GPUs in the authoring loop, and the first contact should be with the most ordinary collective; the
+		# fan-out is an option to measure against it (bench.py --transport fanout / STPY_DIST_TRANSPORT=fanout).
 		if self._transport_arg == "fanout":
 			self.transport = "fanout"
 		elif self._transport_arg == "auto" and dist.get_backend() == "nccl" and self.world > 1 and self._peer_access_everywhere():

@@ -161,3 +161,18 @@ def test_dtv_kernel_fragments_are_not_copied(tmp_path):
 		mf = [k for k, l in enumerate(body) if "v_mfma" in l]
 		moves = [l.strip() for l in body[mf[0]:mf[-1]] if re.match(r"\s*v_(mov|accvgpr|pk_mov)", l)]
 		assert not moves, (name, moves[:4])
+
+
+def test_bench_always_prints_one_json_line():
+	"""`python bench.py --gpus 8` on a box without eight GPUs (this container has none): the self-launched ranks fail, and the
+	one line the driver reads is still there -- value null and the reason -- with a non-zero exit code."""
+	import json
+	import sys
+	env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+	assert len(lines) == 1, r.stdout[-2000:]
+	out = json.loads(lines[0])
+	import torch
+	if not torch.cuda.is_available() or torch.cuda.device_count() < 8:
+		assert r.returncode != 0 and out["value"] is None and out["n_gpus"] == 8 and out["error"]

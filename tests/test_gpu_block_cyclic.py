@@ -138,3 +138,27 @@ def test_rff_row_split_on_gpu(gpu_device):
 	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
 	assert got[0][1] == 0 and got[-1][2] == 8192 + 640 and all(got[i][2] == got[i + 1][1] for i in range(world - 1))
 	assert all(e < 2e-5 for (_, _, _, e) in got), got
+
+
+def test_bench_self_launch_two_ranks_gloo():
+	"""`python bench.py --gpus 2` started PLAINLY (no WORLD_SIZE): the script launches its two ranks itself (fresh child processes
+	through torch.distributed.run, before this process has touched the GPU), relays rank 0's single JSON line and the children's
+	exit code.  Rehearsal backend: the ranks share the one GPU of the test box and the collectives are staged through the host."""
+	import json
+	import subprocess
+	import sys
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	env = dict(os.environ, STPY_BENCH_BACKEND="gloo")
+	for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+		env.pop(k, None)
+	r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "4096", "--no-cpu-baseline"],
+					   capture_output=True, text=True, timeout=600, env=env, cwd=root)
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+	assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+	out = json.loads(lines[0])
+	assert out["n_gpus"] == 2 and out["value"] is not None and out["value"] > 0 and out["steps"] == 1 and out["warmup"] == 0
+	assert out["scaling"] == "strong" and out["higher_is_better"] is False and out["unit"] == "s"
+	mg = out["multi_gpu"]
+	assert mg["backend"] == "gloo" and mg["grid"] == "1x2" and len(mg["per_rank"]) == 2
+	assert mg["selfcheck"]["mu_rel_err_vs_single_gpu_class"] < 1e-8 and mg["selfcheck"]["sigma_rel_err"] < 1e-8
+	assert not out["result_check"]["nan"]

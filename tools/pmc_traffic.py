@@ -1,7 +1,16 @@
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py into the per-launch HBM
 traffic of the GEMM kernel that bench.py reports as roofline.traffic.
-usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
-import collections, csv, json, re, sys
+usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+The record carries the version string of the library the passes ran with (stpy_version(): it contains a hash of the kernel
+sources), so that bench.py pairs it only with runs of the same build."""
+import collections, csv, ctypes, json, os, re, sys
+
+
+def library_version():
+	here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	lib = ctypes.CDLL(os.path.join(here, "stpy_amd", "libstpy_hip.so"))
+	lib.stpy_version.restype = ctypes.c_char_p
+	return lib.stpy_version().decode()
 
 def collect(path, counter):
 	per = collections.defaultdict(lambda: [0, 0.0])
@@ -25,6 +34,7 @@ def main():
 	total = 2.0 * f_bytes + w_bytes
 	out = {
 		"_what": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` (N=65536, d=16, M=4096, fp64); all dispatches of stpy::gemm_nt_dtv_kernel<...> and stpy::gemm_nt_kernel<double,...> summed",
+		"library_version": library_version(),
 		"gemm_launches": launches, "FETCH_SIZE_bytes_raw": f_bytes, "WRITE_SIZE_bytes": w_bytes, "hbm_bytes_corrected": total,
 		"correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streams (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE exact. The 8-byte-per-lane C-tile reads are not a calibrated access width, so 2x is an upper bound for them.",
 		"per_launch_hbm_bytes": total / max(launches, 1),

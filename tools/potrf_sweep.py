@@ -31,7 +31,7 @@ def main():
 		il = torch.full((d,), 0.25, dtype=dt, device=dev)
 		K = torch.empty(n, n, dtype=dt, device=dev)
 		winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=dt, device=dev)
-		work = torch.empty(max(int(lib.stpy_potrf_workspace_bytes(code, n, nb)), 2 * n * 2048 * esz), dtype=torch.uint8, device=dev)          # (widest panel any policy picks)
+		work = torch.empty(max(int(lib.stpy_potrf_workspace_bytes(code, n, nb)), 2 * n * 4096 * esz), dtype=torch.uint8, device=dev)          # (widest panel any policy picks)
 		info = torch.zeros(1, dtype=torch.int32, device=dev)
 		ws = torch.empty(int(lib.stpy_gram_workspace_bytes(code, n, n, d)), dtype=torch.uint8, device=dev)
 
