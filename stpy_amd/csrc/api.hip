@@ -373,6 +373,7 @@ void stpy_tune(int key, int value)
 	case 9: if (STPY_LAB || value != 3) g_rff_tile = value; return;          // (3 = the direct-store streaming variant: lab build only)
 	case 16: g_trsv_flow = value; return;
 	case 17: g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0; return;
+	case 26: g_gemm_bf3 = value; return;
 	default: break;
 	}
 #if STPY_LAB
@@ -393,6 +394,7 @@ int stpy_tune_get(int key)
 	case 9: return g_rff_tile;
 	case 16: return g_trsv_flow;
 	case 17: return g_trsm_strip;
+	case 26: return g_gemm_bf3;
 	default: break;
 	}
 #if STPY_LAB

@@ -38,6 +38,7 @@ template <typename T> struct KTile { static constexpr int BK = 128 / (int)sizeof
                                // tools/potrf_sweep.py "20=0|1" shows no difference at any size -- 1370.07 vs 1370.03 ms at N = 65 536)
 // g_gemm_dtv = 1:             A operand direct to VGPR for aligned fp64 products with at least this many tiles (stpy_tune key 6; 0 = never)
 // g_gemm_dtv_min_k = 64
+int g_gemm_bf3 = 64;             // fp32: aligned plain products with at least this many tiles run on the bf16 matrix cores (stpy_tune key 26; 0 = never)
 int g_gemm_k128 = 768;           // K = 128 products with at most this many 64 x 64 tiles take the one-volley kernel (stpy_tune key 8; 0 = never)
 // g_gemm_exp = 0:             timing experiments only, lab build (results are wrong when != 0)
 #if STPY_LAB
@@ -907,6 +908,161 @@ void gemm_nt_dtv_kernel(GemmArgs<T> p)
 }
 
 // ------------------------------------------------------------------------------------------
+// fp32 products on the bf16 MATRIX cores (aligned plain / lower-triangular products, fp32 in, fp32 out).
+// v_mfma_f32_16x16x4_f32 runs on the SIMD's own fp32 lanes at the packed-fp32 vector rate (157 TFLOP/s, shared with every VALU
+// instruction next to it); the bf16 matrix pipe is a separate unit at 16x that rate.  Every fp32 operand value is split EXACTLY into
+// three bf16 parts (x = x1 + x2 + x3: 8 + 8 + 8 significant bits, by truncation -- no rounding anywhere), and the six products of
+// weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16, smallest first:
+//     a.b = a1 b3 + a1 b2 + a2 b2 + a1 b1 + a2 b1 + a3 b1      (dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a||b|, below one fp32 rounding
+//                                                               of the product -- the recipe of rff_stream_bf16x3_kernel, rff.hip)
+// 96 bf16 MFMAs (1536 cycles) per 64 x 64 x 32 wave step replace 256 fp32 MFMAs (8192 cycles): a 390 TFLOP/s ceiling.
+// The split is done ON THE FLY, once per workgroup and K step: thread t takes 16 consecutive k of row t/2 of the A tile and of the
+// B tile from global memory into registers (the loads of step k+1 are in flight under the MFMAs of step k), splits them (4 VALU
+// operations per value + 3 byte-permutes per pair) and writes the three bf16 planes of both tiles to LDS (48 KiB per workgroup:
+// two or three workgroups per CU, whose split / MFMA phases interleave on the two pipes).  Plane rows are 64 bytes (32 bf16); the
+// 16-byte chunk c of row r lives at c ^ ((r >> 1) & 3), which makes the ds_read_b128 fragment reads conflict-free.
+// No operand is pre-split in memory, so every aligned fp32 product of the path takes this kernel unchanged: the trailing updates of
+// potrf, the block solve, the feature-space SYRK of KernelizedFeatures.
+// ------------------------------------------------------------------------------------------
+constexpr int B3_BK = 32;                                  // fp32 values per K step = one bf16 MFMA k-extent
+constexpr int B3_PLANE = (BM + BN) * B3_BK * 2;           // bytes of one bf16 plane of both tiles: 16 KiB
+// Two structurally different forms were built and measured against this one in one process (tools/f32_gemm_bench.py, trailing update
+// n = 32 768, K = 1024: this kernel 191-195 TFLOP/s, the fp32-MFMA kernel 140): (a) ONE workgroup per CU, planes double-buffered,
+// the split of step k+1 interleaved instruction by instruction with the MFMAs of step k in the same wave -- 120 TFLOP/s: an in-order
+// wave that stops at an LDS store or a wait stops its MFMAs too; (b) a 512-thread workgroup with four MFMA-only waves and four
+// load / split / store waves meeting at one barrier per step -- 176-184 TFLOP/s: no better than two independent workgroups whose
+// phases drift apart by themselves.  Neither is kept.
+// (Three workgroups per CU would need <= 168 VGPRs; the kernel wants 186 -- 64 accumulators, 96 fragments, 32 raw values in
+// flight -- and spills 18-34 of them when capped, with or without the fragment reads issued group by group.  Two per CU.)
+template <int ACC>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_nt_bf3_kernel(GemmArgs<float> p)
+{
+	constexpr bool SUB = ACC == 1, LOADC = ACC != 0;
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+	typedef unsigned u4v __attribute__((ext_vector_type(4)));
+	__shared__ __attribute__((aligned(16))) unsigned char smem[3 * B3_PLANE];          // [part][A rows 0..127 | B rows 128..255][64 B]
+
+	// ---- block -> tile: the XCD-local super-tile map of the kernels above (plain rectangle or lower triangle)
+	const int b = blockIdx.x;
+	const int S = (b & 7) + 8 * (b >> 9);
+	const int w = (b >> 3) & 63;
+	if (S >= p.nsuper) return;
+	int si, sj;
+	if (p.tri) {
+		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
+		while ((si + 1) * (si + 2) / 2 <= S) ++si;
+		while (si * (si + 1) / 2 > S) --si;
+		sj = S - si * (si + 1) / 2;
+	} else {
+		si = S / p.nst_n;
+		sj = S - si * p.nst_n;
+	}
+	const int ti = __builtin_amdgcn_readfirstlane(si * p.st_m + w / p.st_n);
+	const int tj = __builtin_amdgcn_readfirstlane(sj * p.st_n + w % p.st_n);
+	if (ti >= p.tiles_m || tj >= p.tiles_n) return;
+	if (p.tri && tj > ti) return;
+	const int row0 = ti * BM, col0 = tj * BN;
+	const int kbeg = p.kskip ? row0 : 0;
+	const int KT = (p.k - kbeg) / B3_BK;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
+
+	// ---- global -> registers: thread t owns k = 16 (t & 1) .. + 15 of tile row t >> 1, of A and of B
+	const int srow = tid >> 1, shalf = tid & 1;
+	const float* const ga = p.A + (int64_t)(row0 + srow) * p.lda + kbeg + 16 * shalf;
+	const float* const gb = p.B + (int64_t)(col0 + srow) * p.ldb + kbeg + 16 * shalf;
+	v4f ra[4], rb[4];
+	auto gload = [&](int k0) {
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { ra[q] = *(const v4f*)(ga + k0 + 4 * q); rb[q] = *(const v4f*)(gb + k0 + 4 * q); }
+	};
+	// ---- split + store: 16 values -> 3 parts x 16 bf16 = 3 x two 16-byte chunks (logical chunks 2 shalf, 2 shalf + 1 of the row)
+	const int swz = (srow >> 1) & 3;
+	auto split_store = [&](const v4f (&r)[4], int rowbase) {
+		unsigned part[3][8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {            // value pair (2q, 2q + 1)
+			unsigned h[2][3];
+#pragma unroll
+			for (int e = 0; e < 2; ++e) {
+				const float x = r[(2 * q + e) >> 2][(2 * q + e) & 3];
+				const unsigned u1 = __float_as_uint(x) & 0xffff0000u;
+				const float r1 = x - __uint_as_float(u1);                  // exact: the low 16 significant bits
+				const unsigned u2 = __float_as_uint(r1) & 0xffff0000u;
+				const float r2 = r1 - __uint_as_float(u2);                 // exact: at most 8 significant bits left
+				h[e][0] = u1; h[e][1] = u2; h[e][2] = __float_as_uint(r2);
+			}
+#pragma unroll
+			for (int pt = 0; pt < 3; ++pt) part[pt][q] = __builtin_amdgcn_perm(h[1][pt], h[0][pt], 0x07060302u);          // high halves: [odd value | even value]
+		}
+#pragma unroll
+		for (int pt = 0; pt < 3; ++pt) {
+			unsigned char* const rowp = smem + pt * B3_PLANE + (rowbase + srow) * 64;
+			*(u4v*)(rowp + (((2 * shalf) ^ swz) << 4)) = u4v{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+			*(u4v*)(rowp + (((2 * shalf + 1) ^ swz) << 4)) = u4v{part[pt][4], part[pt][5], part[pt][6], part[pt][7]};
+		}
+	};
+
+	gload(0);
+	// ---- accumulators: zero, or the C tile (negated when subtracting: the products are accumulated on -C and the sign flipped at the store)
+	v4f acc[4][4];
+	float* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
+	const unsigned ldc32 = (unsigned)p.ldc;
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) { const float v = LOADC ? crow[tn * 16] : 0.f; acc[tm][tn][i] = SUB ? -v : v; }
+		}
+	split_store(ra, 0);
+	split_store(rb, BM);
+	__syncthreads();
+
+	// fragment reads: lane (r16, kq) takes chunk kq of row r16 of a 16-row tile: physical chunk kq ^ ((r16 >> 1) & 3)
+	const unsigned frag = (unsigned)r16 * 64u + (unsigned)((kq ^ ((r16 >> 1) & 3)) << 4);
+	const unsigned a_off = (unsigned)(wm * 64) * 64u + frag, b_off = (unsigned)(BM + wn * 64) * 64u + frag;
+	constexpr int AP[6] = {0, 0, 1, 0, 1, 2}, BP[6] = {2, 1, 1, 0, 0, 0};
+	for (int kt = 0; kt < KT; ++kt) {
+		if (kt + 1 < KT) gload((kt + 1) * B3_BK);
+		bf8 fa[3][4], fb[3][4];
+#pragma unroll
+		for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+			for (int t = 0; t < 4; ++t) {
+				fa[pt][t] = __builtin_bit_cast(bf8, *(const u4v*)(smem + pt * B3_PLANE + a_off + t * 16 * 64));
+				fb[pt][t] = __builtin_bit_cast(bf8, *(const u4v*)(smem + pt * B3_PLANE + b_off + t * 16 * 64));
+			}
+#pragma unroll
+		for (int g = 0; g < 6; ++g)
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn)
+					acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[AP[g]][tm], fb[BP[g]][tn], acc[tm][tn], 0, 0, 0);
+		__syncthreads();                       // every wave has read this step's planes
+		if (kt + 1 < KT) {
+			split_store(ra, 0);
+			split_store(rb, BM);
+			__syncthreads();
+		}
+	}
+	// (C may alias A -- the block solve multiplies in place: all of A's contribution is in the accumulators, and the barrier above
+	// has every wave past its last operand load)
+#pragma unroll
+	for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) crow[tn * 16] = SUB ? -acc[tm][tn][i] : acc[tm][tn][i];
+		}
+}
+
+// ------------------------------------------------------------------------------------------
 // K = 128 products on small grids (the panel chain of the factorisation and of the block solve: a row block
 // times an inverse diagonal block, C may alias A).  Through the kernels above such a launch is a chain of eight
 // K tiles on a few dozen workgroups, each tile waiting a full memory latency with nothing to hide it: 45-90 us
@@ -1367,6 +1523,18 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 			if (mode == 1) hipLaunchKernelGGL((gemm_nt_k128_kernel<true>), g64, block, 0, st, p);
 			else hipLaunchKernelGGL((gemm_nt_k128_kernel<false>), g64, block, 0, st, p);
 			return check_launch("gemm_nt");
+		}
+	}
+	if constexpr (sizeof(T) == 4) {
+		// fp32 products on the bf16 matrix cores (exact three-way split, see gemm_nt_bf3_kernel): aligned shapes from 64 tiles on
+		// (below that the launch is latency-bound either way and the fp32-MFMA kernels keep their tuned small-grid forms)
+		const int64_t ntiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n;
+		if (g_gemm_bf3 > 0 && ntiles >= g_gemm_bf3 && aligned && (mode == 0 || mode == 1 || mode == 5) && !bc && !C2 && p.ksplit == 1 && !g_gemm_exp &&
+		    k >= 2 * B3_BK && p.tri != 2 && ldc < ((int64_t)1 << 31)) {
+			if (mode == 1) hipLaunchKernelGGL((gemm_nt_bf3_kernel<1>), grid, block, 0, st, p);
+			else if (mode == 5) hipLaunchKernelGGL((gemm_nt_bf3_kernel<2>), grid, block, 0, st, p);
+			else hipLaunchKernelGGL((gemm_nt_bf3_kernel<0>), grid, block, 0, st, p);
+			return check_launch("gemm_nt (bf16x3)");
 		}
 	}
 	{

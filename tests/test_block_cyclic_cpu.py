@@ -118,10 +118,16 @@ def test_block_cyclic_matches_oracle(world, grid, n, nb_dist, kernel_name, nu):
 	assert stats["collectives"] > 0 and stats["bcast_bytes"] > 0
 
 
-@pytest.mark.parametrize("world,grid,n", [(2, (1, 2), 520), (2, (2, 1), 520), (4, (2, 2), 900), (6, (2, 3), 1100), (6, (3, 2), 1100), (8, (2, 4), 1700), (8, (4, 2), 1300)])
-@pytest.mark.parametrize("opts", [{"transport": "collective", "col_exchange": "allgather"}, {"transport": "fanout", "col_exchange": "allgather"},
-								  {"transport": "collective", "col_exchange": "bcast"}, {"transport": "fanout", "col_exchange": "bcast"}],
-						 ids=["bcast+allgather", "fanout+allgather", "bcast+bcast", "fanout+bcast"])
+_AG, _FA, _BB, _FB = ({"transport": "collective", "col_exchange": "allgather"}, {"transport": "fanout", "col_exchange": "allgather"},
+					  {"transport": "collective", "col_exchange": "bcast"}, {"transport": "fanout", "col_exchange": "bcast"})
+
+
+@pytest.mark.parametrize("world,grid,n,opts", [
+	(2, (1, 2), 520, _AG), (2, (1, 2), 520, _FA), (2, (2, 1), 520, _AG), (2, (2, 1), 520, _FB),
+	(4, (2, 2), 900, _AG), (4, (2, 2), 900, _FA), (4, (2, 2), 900, _BB), (4, (2, 2), 900, _FB),
+	(6, (2, 3), 1100, _AG), (6, (3, 2), 1100, _FA), (6, (3, 2), 1100, _BB),
+	(8, (2, 4), 1700, _AG), (8, (2, 4), 1700, _FA), (8, (2, 4), 1700, _BB), (8, (4, 2), 1300, _AG), (8, (4, 2), 1300, _FB),
+], ids=lambda v: ("%s+%s" % (v["transport"], v["col_exchange"])) if isinstance(v, dict) else None)
 def test_collective_order_audit(world, grid, n, opts):
 	"""What hangs on RCCL and passes on host-staged gloo is a member of a communicator issuing a different sequence of collectives
 	than its peers.  Every rank logs, per communicator (process row, process column, world), the sequence of (operation, root,

@@ -70,6 +70,44 @@ def test_gemm_nt_accumulate_lower(L, dtype, tol):
 	assert np.isnan(got[~low]).all()
 
 
+@pytest.mark.parametrize("m,n,k,lower", [(1024, 1024, 512, 0), (2048, 512, 1024, 0), (1536, 1536, 256, 1), (1024, 1024, 64, 0)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_nt_f32_on_bf16_matrix_cores(L, m, n, k, lower, mode):
+	"""Aligned fp32 products of >= 64 tiles run on the bf16 matrix cores from an EXACT three-way split of both operands (six
+	products, fp32 accumulation; stpy_tune route key 26, 0 = the fp32-MFMA kernels).  Against fp64 numpy the result must be as
+	accurate as the fp32-MFMA kernel's, on data that stresses the split: six decades of dynamic range inside a row, exact zeros,
+	mixed signs, values with all 24 significand bits set."""
+	lib = L.load()
+	rng = np.random.RandomState(m + n + k + 7 * mode + lower)
+	def stress(shape):
+		a = rng.normal(size=shape) * 10.0 ** rng.uniform(-3, 3, size=shape)
+		a[rng.uniform(size=shape) < 0.05] = 0.0
+		a = a.astype(np.float32)
+		a.view(np.uint32)[::7, ::5] |= np.uint32(0x007fffff)          # full significands
+		return a
+	A, B, C = stress((m, k)), stress((n, k)), (rng.normal(size=(m, n)) * 1e3).astype(np.float32)
+	ref64 = A.astype(np.float64) @ B.astype(np.float64).T
+	ref = ref64 if mode == 0 else (C.astype(np.float64) - ref64 if mode == 1 else C.astype(np.float64) + ref64)
+	scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T + np.abs(C) * (mode != 0)          # elementwise error scale
+	outs = {}
+	assert lib.stpy_tune_get(26) > 0
+	try:
+		for route in (lib.stpy_tune_get(26), 0):
+			lib.stpy_tune(26, route)
+			Ad, Bd, Cd = dev(A, torch.float32), dev(B, torch.float32), dev(C, torch.float32)
+			L.check(lib.stpy_gemm_nt(L.F32, m, n, k, L.ptr(Ad), k, L.ptr(Bd), k, L.ptr(Cd), n, mode, lower, L.stream_ptr()), "gemm")
+			outs[route] = Cd.cpu().numpy().astype(np.float64)
+	finally:
+		lib.stpy_tune(26, 64)
+	tiles = np.arange(m)[:, None] // 128 >= np.arange(n)[None, :] // 128 if lower else np.ones((m, n), bool)
+	errs = {r: float(np.max(np.abs(o - ref)[tiles] / scale[tiles])) for r, o in outs.items()}
+	bf3, f32 = errs[[r for r in errs if r][0]], errs[0]
+	assert bf3 < 4e-6 and bf3 <= 2.0 * f32 + 1e-7, errs
+	if lower:          # tiles above the diagonal untouched
+		for o in outs.values():
+			assert np.array_equal(o[~tiles], C.astype(np.float64)[~tiles])
+
+
 @pytest.mark.parametrize("m,n,k,mode", [(1, 512, 4096, 0), (1, 300, 1001, 1), (2, 128, 640, 0), (3, 257, 96, 1), (5, 64, 2048, 0), (8, 512, 1536, 1)])
 def test_gemm_nt_skinny_rows(L, m, n, k, mode):
 	"""m <= 8 goes to the bandwidth-bound row kernel (z = L^-1 y on the distributed path)."""
