@@ -1026,7 +1026,17 @@ void gemm_nt_bf3_kernel(GemmArgs<float> p)
 	const unsigned frag = (unsigned)r16 * 64u + (unsigned)((kq ^ ((r16 >> 1) & 3)) << 4);
 	const unsigned a_off = (unsigned)(wm * 64) * 64u + frag, b_off = (unsigned)(BM + wn * 64) * 64u + frag;
 	constexpr int AP[6] = {0, 0, 1, 0, 1, 2}, BP[6] = {2, 1, 1, 0, 0, 0};
-	for (int kt = 0; kt < KT; ++kt) {
+	// Two-level accumulation.  The bf16 MFMA does not round its accumulate to nearest: measured against fp64, a sum carried in the
+	// MFMA accumulator loses about half an ulp OF THE ACCUMULATOR per instruction, always toward zero -- 768 instructions of a
+	// K = 4096 product on an accumulator that starts at C cost 4.5x the error of the fp32-MFMA kernel, and over a whole fp32
+	// factorisation (tens of thousands of instructions onto each element) the bias reached 1e-4 relative and made a well
+	// conditioned feature-space matrix fail its Cholesky.  So the MFMAs accumulate B3_CHUNK K steps at a time into a FRESH
+	// accumulator (`part`, started from the zero constant: its magnitude, hence its ulp, is that of a 128-deep partial sum, not of C),
+	// and the partial sums are added to the real accumulator by the vector ALU, which rounds to nearest (64 additions per 384 MFMAs).
+	constexpr int B3_CHUNK = 4;
+	v4f part[4][4];
+	auto kstep = [&](auto first_tag, int kt) {
+		constexpr bool FIRST = decltype(first_tag)::value;
 		if (kt + 1 < KT) gload((kt + 1) * B3_BK);
 		bf8 fa[3][4], fb[3][4];
 #pragma unroll
@@ -1042,13 +1052,21 @@ void gemm_nt_bf3_kernel(GemmArgs<float> p)
 			for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
 				for (int tn = 0; tn < 4; ++tn)
-					acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[AP[g]][tm], fb[BP[g]][tn], acc[tm][tn], 0, 0, 0);
+					part[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[AP[g]][tm], fb[BP[g]][tn], (FIRST && g == 0) ? v4f{0.f, 0.f, 0.f, 0.f} : part[tm][tn], 0, 0, 0);
 		__syncthreads();                       // every wave has read this step's planes
 		if (kt + 1 < KT) {
 			split_store(ra, 0);
 			split_store(rb, BM);
 			__syncthreads();
 		}
+	};
+	for (int kc = 0; kc < KT; kc += B3_CHUNK) {
+		kstep(std::true_type{}, kc);
+		for (int j = 1; j < B3_CHUNK && kc + j < KT; ++j) kstep(std::false_type{}, kc + j);
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) acc[tm][tn] += part[tm][tn];
 	}
 	// (C may alias A -- the block solve multiplies in place: all of A's contribution is in the accumulators, and the barrier above
 	// has every wave past its last operand load)

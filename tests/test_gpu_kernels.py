@@ -70,13 +70,15 @@ def test_gemm_nt_accumulate_lower(L, dtype, tol):
 	assert np.isnan(got[~low]).all()
 
 
-@pytest.mark.parametrize("m,n,k,lower", [(1024, 1024, 512, 0), (2048, 512, 1024, 0), (1536, 1536, 256, 1), (1024, 1024, 64, 0)])
+@pytest.mark.parametrize("m,n,k,lower", [(1024, 1024, 512, 0), (2048, 512, 1024, 0), (1536, 1536, 256, 1), (1024, 1024, 64, 0), (1024, 1024, 8192, 0)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_nt_f32_on_bf16_matrix_cores(L, m, n, k, lower, mode):
 	"""Aligned fp32 products of >= 64 tiles run on the bf16 matrix cores from an EXACT three-way split of both operands (six
 	products, fp32 accumulation; stpy_tune route key 26, 0 = the fp32-MFMA kernels).  Against fp64 numpy the result must be as
 	accurate as the fp32-MFMA kernel's, on data that stresses the split: six decades of dynamic range inside a row, exact zeros,
-	mixed signs, values with all 24 significand bits set."""
+	mixed signs, values with all 24 significand bits set.  K = 8192 is the long-accumulation case: the bf16 MFMA's accumulate is not
+	round-to-nearest (half an ulp of the accumulator lost per instruction, toward zero), which is why the kernel carries only
+	128-deep partial sums in the MFMA accumulator and adds them on the vector ALU -- without that this case fails by 4-5x."""
 	lib = L.load()
 	rng = np.random.RandomState(m + n + k + 7 * mode + lower)
 	def stress(shape):
