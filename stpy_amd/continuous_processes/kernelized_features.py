@@ -16,7 +16,8 @@ rank 2: at BASELINE config 5's shape it would be 34 GB):
     Phi^T y     stpy_predict (row sums against y),   theta: stpy_trsv forward + backward
     X = Phi* L^-T      stpy_trsm_right_lt,   mean = X (L^-1 Phi^T y),  std = s sqrt(rowsum(X o X))
 The dual form (n < m with primal=False), the Woodbury/Schur rank-one updates of ``add_data_point``
-(refit here), Matheron sampling, and the cvxpy-based constrained fits are outside the hot path.
+(here: the accumulated normal equations are extended by the new rows and refactored), Matheron sampling, and the cvxpy-based
+constrained fits are outside the hot path.
 """
 import numpy as np
 import torch
@@ -60,6 +61,7 @@ class KernelizedFeatures:
 		self.nb = 0
 		self.slab_bytes = 2 << 30          # features held at a time while V and Phi^T y are accumulated (fit_gp)
 		self._L = self._winv = self._u = self._theta = None
+		self._Vacc = self._rhs = self._part = None          # accumulated Phi^T Phi (lower tiles) and Phi^T y: what add_data_point extends
 
 	# ------------------------------------------------------------------ small API mirrors
 	def description(self):
@@ -101,58 +103,68 @@ class KernelizedFeatures:
 
 	# ------------------------------------------------------------------ fit
 	def add_data_point(self, x, y):
-		"""kernelized_features.py:107-112 (the reference queues a rank-one update; here: concatenate and refit)."""
-		if self.n == 0:
+		"""kernelized_features.py:107-112 (the reference queues rank-one updates of V^-1).  Here the accumulated normal equations are
+		kept (Phi^T Phi and Phi^T y, see fit_gp), so k new rows cost their embedding, one k-deep `+=` product and the m x m
+		refactorisation -- not a pass over all n rows."""
+		if self.n == 0 or self._Vacc is None:
 			self.fit_gp(x, y)
-		else:
-			self.fit_gp(torch.cat((self.x, x), dim=0), torch.cat((self.y, y), dim=0))
+			return
+		self.x = torch.cat((self.x, x), dim=0)
+		self.y = torch.cat((self.y, y), dim=0)
+		self.n = list(self.x.size())[0]
+		xd = _lib.to_device(x, self._Vacc.dtype)
+		yd = _lib.to_device(y, self._Vacc.dtype).reshape(-1)
+		self._accumulate(xd, yd, first=False)
+		self._solve_normal_equations()
 
 	def fit(self, x=None, y=None):
 		self.fit_gp(self.x if x is None else x, self.y if y is None else y)
 
-	def fit_gp(self, x, y):
-		"""kernelized_features.py:118-138 + :236-240, streaming over row slabs of x (see the module header)."""
+	def _accumulate(self, xd, yd, first):
+		"""V_acc (+)= Phi^T Phi (lower tiles) and rhs (+)= Phi^T y over row slabs of xd; ``first``: the buffers are (re)created."""
 		lib = _lib.load()
-		self.x, self.y = x, y
-		self.n = list(x.size())[0]
-		self.d = list(x.size())[1]
-		self.data = True
-		xd = _lib.to_device(x)
-		yd = _lib.to_device(y, xd.dtype).reshape(-1)
 		n = xd.shape[0]
 		esz = xd.element_size()
 		st = _lib.stream_ptr
 		dt = _lib.dtype_code(xd.dtype)
-		V = rhs = part = None
-		m = None
+		m = None if first else self._Vacc.shape[0]
+		rows = n if first else max(128, (int(self.slab_bytes) // (m * esz)) // 128 * 128)
 		r0 = 0
-		rows = n          # slab height: set once the feature count is known (first slab: a probe of at most 4096 rows)
-		first = True
 		while r0 < n:
-			take = min(4096 if first and m is None else rows, n - r0)
+			take = min(4096 if m is None else rows, n - r0)          # (first slab of a fit: a probe that tells the feature count)
 			PhiT = _lib.to_device(self._embed_t(xd[r0:r0 + take]), xd.dtype)            # (m, take)
 			if PhiT.stride(1) != 1:
 				PhiT = PhiT.contiguous()
 			if m is None:
 				m = PhiT.shape[0]
 				rows = max(128, (int(self.slab_bytes) // (m * esz)) // 128 * 128)
-				V = torch.empty((m, m), dtype=xd.dtype, device=xd.device)
-				rhs = torch.empty((1, m), dtype=xd.dtype, device=xd.device)
-				part = torch.empty((1, m), dtype=xd.dtype, device=xd.device)
-			# V (+)= Phi_slab^T Phi_slab, lower tiles only: mode 0 for the first slab, 2 (accumulate) afterwards
+				self._Vacc = torch.empty((m, m), dtype=xd.dtype, device=xd.device)
+				self._rhs = torch.empty((1, m), dtype=xd.dtype, device=xd.device)
+				self._part = torch.empty((1, m), dtype=xd.dtype, device=xd.device)
+			V = self._Vacc
+			# V (+)= Phi_slab^T Phi_slab, lower tiles only: mode 0 for the first slab of a fit, 2 (accumulate) afterwards
 			_lib.check(lib.stpy_gemm_nt(dt, m, m, take, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(V), V.stride(0),
 										0 if first else 2, 1, st()), "stpy_gemm_nt")
 			# Phi_slab^T y_slab: row sums of Phi^T against y
 			ys = yd[r0:r0 + take]
-			tgt = rhs if first else part
+			tgt = self._rhs if first else self._part
 			_lib.check(lib.stpy_predict(dt, m, take, _lib.ptr(PhiT), PhiT.stride(0), _lib.ptr(ys), None, _lib.ptr(tgt), None, 0, st()), "stpy_predict")
 			if not first:
-				_lib.check(lib.stpy_combine(dt, 1, m, _lib.ptr(rhs), m, _lib.ptr(part), m, _lib.OUT_ADD, 0.0, st()), "stpy_combine")
+				_lib.check(lib.stpy_combine(dt, 1, m, _lib.ptr(self._rhs), m, _lib.ptr(self._part), m, _lib.OUT_ADD, 0.0, st()), "stpy_combine")
 			first = False
 			r0 += take
 			del PhiT
-		# + s^2 lam on the diagonal (an in-place pass of the elementwise kernel: out = out, then the diagonal term)
-		_lib.check(lib.stpy_combine(dt, m, m, _lib.ptr(V), V.stride(0), _lib.ptr(V), V.stride(0), _lib.OUT_SET, float(self.s) ** 2 * float(self.lam), st()), "stpy_combine")
+
+	def _solve_normal_equations(self):
+		"""V = V_acc + s^2 lam I -> Cholesky, u = L^-1 (Phi^T y), theta = L^-T u."""
+		lib = _lib.load()
+		st = _lib.stream_ptr
+		Vacc = self._Vacc
+		m = Vacc.shape[0]
+		dt = _lib.dtype_code(Vacc.dtype)
+		V = torch.empty_like(Vacc)
+		# V = V_acc, then + s^2 lam on the diagonal (one pass of the elementwise kernel)
+		_lib.check(lib.stpy_combine(dt, m, m, _lib.ptr(V), V.stride(0), _lib.ptr(Vacc), Vacc.stride(0), _lib.OUT_SET, float(self.s) ** 2 * float(self.lam), st()), "stpy_combine")
 		self._Vlow = V.clone()                                         # lower triangle of V, for the ``V`` property
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(m)),), dtype=V.dtype, device=V.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, m, self.nb)),), dtype=torch.uint8, device=V.device)
@@ -160,9 +172,9 @@ class KernelizedFeatures:
 		_lib.check(lib.stpy_potrf(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), st()), "stpy_potrf")
 		bad = int(info.item())
 		if bad != 0:
+			self.fitted = False
 			raise torch.linalg.LinAlgError("KernelizedFeatures: Phi^T Phi + s^2 lam I is not positive definite (leading minor %d)" % bad)
-		# u = L^-1 (Phi^T y), theta = L^-T u
-		rhs = rhs.reshape(-1)
+		rhs = self._rhs.reshape(-1).clone()          # (stpy_trsv uses its right-hand side as scratch; the accumulated one is kept)
 		u = torch.empty_like(rhs)
 		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(rhs), _lib.ptr(u), 0, st()), "stpy_trsv")
 		scratch = u.clone()
@@ -170,6 +182,19 @@ class KernelizedFeatures:
 		_lib.check(lib.stpy_trsv(dt, m, _lib.ptr(V), V.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(theta), 1, st()), "stpy_trsv")
 		self._L, self._winv, self._u, self._theta = V, winv, u, theta
 		self.fitted = True
+
+	def fit_gp(self, x, y):
+		"""kernelized_features.py:118-138 + :236-240, streaming over row slabs of x (see the module header)."""
+		self.x, self.y = x, y
+		self.n = list(x.size())[0]
+		self.d = list(x.size())[1]
+		self.data = True
+		xd = _lib.to_device(x)
+		yd = _lib.to_device(y, xd.dtype).reshape(-1)
+		self.fitted = False
+		self._Vacc = self._rhs = self._part = None
+		self._accumulate(xd, yd, first=True)
+		self._solve_normal_equations()
 		return None
 
 	def precompute(self):

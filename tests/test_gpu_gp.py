@@ -1045,3 +1045,31 @@ def test_kernelized_features_streaming_vs_oracle(S, dtype, tol):
 			assert rel_err(N(KF.V), V_o) < 1e-10
 		outs.append((N(mu), N(std)))
 	assert rel_err(outs[0][0], outs[1][0]) < (1e-10 if dtype == torch.float64 else 1e-3)
+
+
+def test_kernelized_features_add_data_point_extends_the_normal_equations(S):
+	"""kernelized_features.py:107-112: new rows extend the accumulated Phi^T Phi / Phi^T y (their embedding + one `+=` product + the
+	m x m refactorisation) -- the same estimator as a fit on all rows, and as the oracle's one-shot normal equations."""
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	rng = np.random.RandomState(78)
+	n, d, m, M = 3000, 4, 256, 100
+	x = rng.uniform(-1, 1, size=(n, d))
+	y = np.cos(x[:, :1] * 2) + 0.1 * rng.normal(size=(n, 1))
+	xt = rng.uniform(-1, 1, size=(M, d))
+	W = rng.normal(size=(m, d))
+	emb = S.RFFEmbedding(gamma=1.0, m=m, d=d)
+	emb.W = torch.from_numpy(W)
+	KF = KernelizedFeatures(embedding=emb, m=m, s=0.2, lam=1.0, d=d)
+	KF.add_data_point(T(x[:1000], True), T(y[:1000], True))          # first call = fit
+	KF.add_data_point(T(x[1000:1003], True), T(y[1000:1003], True))   # a handful of rows
+	KF.add_data_point(T(x[1003:], True), T(y[1003:], True))
+	assert KF.n == n and tuple(KF.x.shape) == (n, d)
+	mu, std = KF.mean_std(T(xt, True))
+	KF2 = KernelizedFeatures(embedding=emb, m=m, s=0.2, lam=1.0, d=d)
+	KF2.fit_gp(T(x, True), T(y, True))
+	mu2, std2 = KF2.mean_std(T(xt, True))
+	assert rel_err(N(mu), N(mu2)) < 1e-10 and rel_err(N(std), N(std2)) < 1e-10
+	Q = O.rff_embed(x, W, m)
+	_, invV, theta = O.kernelized_features_fit(Q, y, 0.2, 1.0)
+	mu_o, std_o = O.kernelized_features_mean_std(O.rff_embed(xt, W, m), invV, theta, 0.2)
+	assert rel_err(N(mu), mu_o) < 1e-8 and rel_err(N(std), std_o) < 1e-8
