@@ -11,9 +11,9 @@ namespace stpy {
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
 // ---- switches ---------------------------------------------------------------------------------------------------------
-// ROUTE switches (stpy_tune keys 5, 8, 9, 16, 17, 26; every build): which of the SHIPPED kernels serves a call where the library
+// ROUTE switches (stpy_tune keys 5, 8, 9, 16, 17, 26, 28; every build): which of the SHIPPED kernels serves a call where the library
 // normally decides by size -- tests/ use them to reach every shipped path at small sizes.  Process-wide, read at launch time.
-extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip, g_gemm_bf3;
+extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip, g_gemm_bf3, g_gram_fill;
 // EXPERIMENT knobs: compile-time constants in the product library (the measured defaults); variables behind stpy_tune only in
 // the lab build (make EXPERIMENTS=1 -> libstpy_hip_lab.so, used by tools/).  The kernels and code paths that only a non-default
 // value reaches are compiled under #if STPY_LAB, so the product library does not carry them.  Where each default comes from is
@@ -110,7 +110,10 @@ template <typename T>
 int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B, int64_t ldb,
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
             const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr, int ksplit = 1, T* split_work = nullptr, int gflags = 0);
-int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);      // recommended number of K passes for a product with few output tiles
+int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);
+// dedicated fp64 Gram fill (gemm.hip): 1 = taken, 0 = not this kernel's shape (the caller falls back to the GEMM epilogue), < 0 = error
+int gram_fill_f64(int kind, const double* as, const double* bs, const double* na, const double* nb, int dpad, int64_t n, int64_t q,
+                  double kappa, double offset, double diag_add, int lower_only, int combine, double* out, int64_t ldo, hipStream_t st);      // recommended number of K passes for a product with few output tiles
 template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st, bool beside = false);
 template <typename T>

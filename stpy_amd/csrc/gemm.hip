@@ -185,6 +185,138 @@ template <typename T, int KIND> __device__ __forceinline__ T gram_dfactor(T acc,
 	return T(1.6666666666666666667) * (T(1) + r) * gram_exp(-r);
 }
 
+// ------------------------------------------------------------------------------------------
+// Dedicated fp64 Gram fill (aligned shapes, overwrite, SE / Matern 3/2 / 5/2 / linear): the HBM-write-bound kernel of the path.
+// Through the GEMM kernel above (EPI = 3) a workgroup owns 128 x 128 outputs, 206 VGPRs and 73 KiB of LDS: two per CU, and the
+// 128 KiB store phase of one overlaps only with the arithmetic of the other (7.1 us per tile pair against 5.3 us of HBM time).
+// Here a workgroup owns 128 x 64 outputs (wave w: rows 32 w .. + 31, all 64 columns: 64 accumulator VGPRs), the scaled points come
+// straight from L2 into registers in MFMA fragment order (they are a few MB in all: no LDS staging, no barrier in the contraction),
+// and the only LDS is the exp table + a wave-private patch that turns a 16-row slab into 16-byte stores of 512 contiguous bytes per
+// row -- 42 KiB and <= 168 VGPRs: three workgroups per CU, so that one is always storing.
+// ------------------------------------------------------------------------------------------
+struct GramFillArgs {
+	const double* as; const double* bs; const double* na; const double* nb; double* out;
+	int64_t ldo; int dpad, nct, lower; double kappa, offset, diag;
+};
+template <int KIND>
+__global__ __launch_bounds__(256, 3)
+void gram_fill_f64_kernel(GramFillArgs p)
+{
+	typedef double T;
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	typedef double d2 __attribute__((ext_vector_type(2)));
+	constexpr int PLD = 80;
+	__shared__ __attribute__((aligned(16))) double smem[GRAM_TAB + 4 * 16 * PLD];
+	double* const tab = smem;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int r16 = lane & 15, g = lane >> 4;
+	tab[tid] = gram_exp(T(tid) * T(0.693147180559945309417 / GRAM_TAB));          // 256 threads, 256 entries
+	// block -> (row tile of 128, column tile of 64); lower: row tile ti holds the 2 (ti + 1) column tiles on or left of its diagonal block
+	int ti, cj;
+	const int b = blockIdx.x;
+	if (p.lower) {
+		ti = (int)((sqrt(4.0 * (double)b + 1.0) - 1.0) * 0.5);
+		while ((ti + 1) * (ti + 2) <= b) ++ti;
+		while (ti * (ti + 1) > b) --ti;
+		cj = b - ti * (ti + 1);
+	} else {
+		ti = b / p.nct;
+		cj = b - ti * p.nct;
+	}
+	ti = __builtin_amdgcn_readfirstlane(ti);
+	cj = __builtin_amdgcn_readfirstlane(cj);
+	const int row0 = ti * 128 + wave * 32, col0 = cj * 64;
+
+	// ---- accumulators start from -(|b_j|^2 + |a_i|^2) / 2 (zero for the linear kernel): they end as -|a_i - b_j|^2 / 2
+	v4 acc[2][4];
+	double ha[4];
+#pragma unroll
+	for (int tn = 0; tn < 4; ++tn) ha[tn] = KIND == STPY_K_LINEAR ? 0.0 : -0.5 * p.na[col0 + tn * 16 + r16];
+#pragma unroll
+	for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const double hb = KIND == STPY_K_LINEAR ? 0.0 : -0.5 * p.nb[row0 + tm * 16 + MM::crow(lane, i)];
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = ha[tn] + hb;
+		}
+	// ---- contraction over the (padded) coordinates: lane (r16, g) holds k = 4 g .. 4 g + 3 of its rows; MFMA s uses element s
+	const double* const bsp = p.bs + (int64_t)(row0 + r16) * p.dpad + 4 * g;
+	const double* const asp = p.as + (int64_t)(col0 + r16) * p.dpad + 4 * g;
+	for (int k0 = 0; k0 < p.dpad; k0 += 16) {
+		d2 fb[2][2], fa[4][2];
+#pragma unroll
+		for (int tm = 0; tm < 2; ++tm) { fb[tm][0] = *(const d2*)(bsp + (int64_t)tm * 16 * p.dpad + k0); fb[tm][1] = *(const d2*)(bsp + (int64_t)tm * 16 * p.dpad + k0 + 2); }
+#pragma unroll
+		for (int tn = 0; tn < 4; ++tn) { fa[tn][0] = *(const d2*)(asp + (int64_t)tn * 16 * p.dpad + k0); fa[tn][1] = *(const d2*)(asp + (int64_t)tn * 16 * p.dpad + k0 + 2); }
+#pragma unroll
+		for (int s = 0; s < 4; ++s)
+#pragma unroll
+			for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn)
+					acc[tm][tn] = MM::mma(fb[tm][s >> 1][s & 1], fa[tn][s >> 1][s & 1], acc[tm][tn]);
+	}
+	__syncthreads();          // the exp table is complete
+	// ---- epilogue, one 16-row slab at a time: kernel function, diagonal term, then the slab's stores (they drain under the next slab's arithmetic)
+	double* const patch = smem + GRAM_TAB + wave * (16 * PLD);
+	const int prow = lane >> 5, pcol = (lane & 31) * 2;
+	const bool on_diag = p.diag != 0.0 && col0 >= ti * 128 && col0 < ti * 128 + 128;
+#pragma unroll
+	for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+		for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) acc[tm][tn][i] = p.kappa * gram_value<double, KIND>(acc[tm][tn][i], tab) + p.offset;
+			__builtin_amdgcn_sched_barrier(0);          // four independent exp chains at a time (see the GEMM epilogue)
+		}
+		if (on_diag) {
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					if (row0 + tm * 16 + MM::crow(lane, i) == col0 + tn * 16 + r16) acc[tm][tn][i] += p.diag;
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int tn = 0; tn < 4; ++tn) patch[MM::crow(lane, i) * PLD + tn * 16 + r16] = acc[tm][tn][i];
+		double* const orow = p.out + (int64_t)(row0 + tm * 16) * p.ldo + col0 + pcol;
+#pragma unroll
+		for (int q = 0; q < 8; ++q) {
+			const int rr = q * 2 + prow;
+			const d2 v = *(const d2*)&patch[rr * PLD + pcol];
+			__builtin_nontemporal_store(v, (d2*)(orow + (int64_t)rr * p.ldo));
+		}
+		__builtin_amdgcn_sched_barrier(0);
+	}
+}
+
+int g_gram_fill = 1;          // stpy_tune route key 28: 1 = the dedicated fp64 fill kernel for aligned overwriting fills, 0 = always the GEMM epilogue
+
+// returns 1 when the dedicated kernel took the fill, 0 when the shape / options are not its, < 0 on a launch error
+int gram_fill_f64(int kind, const double* as, const double* bs, const double* na, const double* nb, int dpad, int64_t n, int64_t q,
+                  double kappa, double offset, double diag_add, int lower_only, int combine, double* out, int64_t ldo, hipStream_t st)
+{
+	if (!g_gram_fill || combine != STPY_OUT_SET || n % 128 != 0 || q % 128 != 0 || dpad % 16 != 0 || ldo % 2 != 0 || (((uintptr_t)out) & 15) != 0 ||
+	    n >= ((int64_t)1 << 30) || q >= ((int64_t)1 << 30) || (lower_only && n != q)) return 0;
+	if (kind != STPY_K_SE && kind != STPY_K_MATERN32 && kind != STPY_K_MATERN52 && kind != STPY_K_LINEAR) return 0;
+	GramFillArgs p{as, bs, na, nb, out, ldo, dpad, (int)(n / 64), lower_only ? 1 : 0, kappa, kind == STPY_K_LINEAR ? offset : 0.0, diag_add};
+	const int64_t qt = q / 128;
+	const int64_t blocks = lower_only ? qt * (qt + 1) : qt * (n / 64);
+	if (blocks > INT32_MAX) return 0;
+	const dim3 grid((unsigned)blocks), block(256);
+	switch (kind) {
+	case STPY_K_SE: hipLaunchKernelGGL(gram_fill_f64_kernel<STPY_K_SE>, grid, block, 0, st, p); break;
+	case STPY_K_MATERN32: hipLaunchKernelGGL(gram_fill_f64_kernel<STPY_K_MATERN32>, grid, block, 0, st, p); break;
+	case STPY_K_MATERN52: hipLaunchKernelGGL(gram_fill_f64_kernel<STPY_K_MATERN52>, grid, block, 0, st, p); break;
+	default: hipLaunchKernelGGL(gram_fill_f64_kernel<STPY_K_LINEAR>, grid, block, 0, st, p); break;
+	}
+	const int rc = check_launch("gram fill");
+	return rc ? rc : 1;
+}
+
 // EPI selects the fused store epilogue at COMPILE time (0 none, 2 RFF trig, 3 Gram kernel function,
 // 4 evidence-gradient weight): the heavy epilogues must not share an instantiation with the plain
 // contraction -- their code raises register pressure enough to push the accumulators of the whole

@@ -213,6 +213,11 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 		else hipLaunchKernelGGL((prep_points_kernel<T>), dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, b, q, ldb, d, dpad, cols, inv_ls, bs, nb);
 		int rc = check_launch("gram prep");
 		if (rc) return rc;
+		if constexpr (sizeof(T) == 8) {          // aligned overwriting fp64 fills: the dedicated kernel (three small workgroups per CU)
+			rc = gram_fill_f64(kind, (const double*)as, (const double*)bs, (const double*)na, (const double*)nb, dpad, n, q, kappa, offset, diag_add, lower_only, combine,
+			                   (double*)out, ldo, st);
+			if (rc != 0) return rc < 0 ? rc : 0;
+		}
 		GramEpilogue<T> epi{kind, combine, (T)kappa, (T)(kind == STPY_K_LINEAR ? offset : 0.0), (T)diag_add, na, nb, nullptr, T(1)};
 		return gemm_nt<T>(q, n, dpad, bs, dpad, as, dpad, out, ldo, (T*)nullptr, 0, 3, lower_only, st, nullptr, nullptr, &epi);
 	}
