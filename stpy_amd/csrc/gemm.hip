@@ -192,14 +192,17 @@ template <typename T, int KIND> __device__ __forceinline__ T gram_dfactor(T acc,
 // Here a workgroup owns 128 x 64 outputs (wave w: rows 32 w .. + 31, all 64 columns: 64 accumulator VGPRs), the scaled points come
 // straight from L2 into registers in MFMA fragment order (they are a few MB in all: no LDS staging, no barrier in the contraction),
 // and the only LDS is the exp table + a wave-private patch that turns a 16-row slab into 16-byte stores of 512 contiguous bytes per
-// row -- 42 KiB and <= 168 VGPRs: three workgroups per CU, so that one is always storing.
+// row -- 22 KiB and <= 128 VGPRs: four workgroups per CU, so that one is always storing.  (Measured, N = 65 536 SE: full fill 7.32 ->
+// 6.87 ms with three workgroups per CU and a 16-row patch; the lower-only fill of fit_gp unchanged at 3.7 ms -- a workgroup's chain
+// of point loads -> MFMAs -> exp -> stores is latency-bound, so residency is what counts: hence the 8-row patch and four per CU.)
 // ------------------------------------------------------------------------------------------
 struct GramFillArgs {
 	const double* as; const double* bs; const double* na; const double* nb; double* out;
 	int64_t ldo; int dpad, nct, lower; double kappa, offset, diag;
 };
+// (the Matern forms -- a square root and more live values per element -- spill 27 registers under the 128 cap: three per CU for them)
 template <int KIND>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, (KIND == STPY_K_SE || KIND == STPY_K_LINEAR) ? 4 : 3)
 void gram_fill_f64_kernel(GramFillArgs p)
 {
 	typedef double T;
@@ -207,7 +210,7 @@ void gram_fill_f64_kernel(GramFillArgs p)
 	typedef MM::v4 v4;
 	typedef double d2 __attribute__((ext_vector_type(2)));
 	constexpr int PLD = 80;
-	__shared__ __attribute__((aligned(16))) double smem[GRAM_TAB + 4 * 16 * PLD];
+	__shared__ __attribute__((aligned(16))) double smem[GRAM_TAB + 4 * 8 * PLD];
 	double* const tab = smem;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int r16 = lane & 15, g = lane >> 4;
@@ -260,7 +263,7 @@ void gram_fill_f64_kernel(GramFillArgs p)
 	}
 	__syncthreads();          // the exp table is complete
 	// ---- epilogue, one 16-row slab at a time: kernel function, diagonal term, then the slab's stores (they drain under the next slab's arithmetic)
-	double* const patch = smem + GRAM_TAB + wave * (16 * PLD);
+	double* const patch = smem + GRAM_TAB + wave * (8 * PLD);
 	const int prow = lane >> 5, pcol = (lane & 31) * 2;
 	const bool on_diag = p.diag != 0.0 && col0 >= ti * 128 && col0 < ti * 128 + 128;
 #pragma unroll
@@ -278,16 +281,21 @@ void gram_fill_f64_kernel(GramFillArgs p)
 				for (int i = 0; i < 4; ++i)
 					if (row0 + tm * 16 + MM::crow(lane, i) == col0 + tn * 16 + r16) acc[tm][tn][i] += p.diag;
 		}
-#pragma unroll
-		for (int i = 0; i < 4; ++i)
-#pragma unroll
-			for (int tn = 0; tn < 4; ++tn) patch[MM::crow(lane, i) * PLD + tn * 16 + r16] = acc[tm][tn][i];
+		// the slab leaves in two halves of 8 rows (registers i = 0, 1: rows g, g + 4; i = 2, 3: rows g + 8, g + 12) through an
+		// 8-row patch: 16-byte stores, 512 contiguous bytes per row, two rows per instruction
 		double* const orow = p.out + (int64_t)(row0 + tm * 16) * p.ldo + col0 + pcol;
 #pragma unroll
-		for (int q = 0; q < 8; ++q) {
-			const int rr = q * 2 + prow;
-			const d2 v = *(const d2*)&patch[rr * PLD + pcol];
-			__builtin_nontemporal_store(v, (d2*)(orow + (int64_t)rr * p.ldo));
+		for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+			for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) patch[(g + 4 * i2) * PLD + tn * 16 + r16] = acc[tm][tn][2 * hf + i2];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int rr = q * 2 + prow;
+				const d2 v = *(const d2*)&patch[rr * PLD + pcol];
+				__builtin_nontemporal_store(v, (d2*)(orow + (int64_t)(8 * hf + rr) * p.ldo));
+			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
 	}

@@ -33,7 +33,7 @@ def test_header_symbols_exported():
 		assert b"lab" not in lib.stpy_version()
 		for key in (0, 1, 2, 6, 11, 12, 18, 20, 21, 22):
 			assert lib.stpy_tune_get(key) == -1, "experiment knob %d is compiled into the product library" % key
-		for key in (5, 8, 9, 16, 17, 26):
+		for key in (5, 8, 9, 16, 17, 26, 28):
 			assert lib.stpy_tune_get(key) >= 0
 
 

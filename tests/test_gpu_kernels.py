@@ -425,6 +425,45 @@ def test_gram_kinds(L, name, kind, n, q, d, use_ws):
 	assert rel_err(out.cpu().numpy(), ref) < 1e-13
 
 
+@pytest.mark.parametrize("kind", [0, 2, 3, 4])
+@pytest.mark.parametrize("d", [3, 16, 40])
+def test_gram_dedicated_fill_kernel(L, kind, d):
+	"""Aligned overwriting fp64 fills take the dedicated fill kernel (stpy_tune route key 28 = 1: 128 x 64 tiles, three workgroups per
+	CU, points straight from L2 in MFMA fragment order): rectangular and lower-only square fills with the diagonal term, against the
+	oracle and against the fused GEMM epilogue (key 28 = 0), to rounding; a padded output leading dimension keeps its padding."""
+	lib = L.load()
+	rng = np.random.RandomState(100 * kind + d)
+	n, q = 384, 640
+	a, b = rng.uniform(-1, 1, size=(n, d)), rng.uniform(-1, 1, size=(q, d))
+	inv_ls = rng.uniform(0.3, 1.5, size=d) if kind != 4 else np.ones(d)
+	ad, bd, ild = dev(a), dev(b), dev(inv_ls)
+	ws = workspace(L, max(n, q), max(n, q), d)
+	WB = ws.numel() * ws.element_size()
+	assert lib.stpy_tune_get(28) == 1
+	outs = {}
+	try:
+		for route in (1, 0):
+			lib.stpy_tune(28, route)
+			out = torch.full((q, n + 2), -7.0, dtype=torch.float64, device="cuda:0")          # leading dimension n + 2: padding must survive
+			L.check(lib.stpy_gram(kind, L.F64, L.ptr(ad), n, d, L.ptr(bd), q, d, d, None, L.ptr(ild), 1.3, 0.25, 0.0, 0, 0,
+								  L.ptr(out), n + 2, L.ptr(ws), WB, L.stream_ptr()), "gram")
+			sq = torch.full((q, q), -7.0, dtype=torch.float64, device="cuda:0")
+			L.check(lib.stpy_gram(kind, L.F64, L.ptr(bd), q, d, L.ptr(bd), q, d, d, None, L.ptr(ild), 0.8, 0.0, 0.37, 1, 0,
+								  L.ptr(sq), q, L.ptr(ws), WB, L.stream_ptr()), "gram")
+			outs[route] = (out.cpu().numpy(), sq.cpu().numpy())
+	finally:
+		lib.stpy_tune(28, 1)
+	ref = oracle_gram(kind, a, b, inv_ls, 1.3, 0.25, None)
+	refsq = oracle_gram(kind, b, b, inv_ls, 0.8, 0.0, None) + 0.37 * np.eye(q)
+	tiles = np.arange(q)[:, None] // 128 >= np.arange(q)[None, :] // 128
+	for route, (o, s2) in outs.items():
+		assert rel_err(o[:, :n], ref) < 1e-13, route
+		assert np.all(o[:, n:] == -7.0), route
+		assert rel_err(s2[tiles], refsq[tiles]) < 1e-13, route
+		assert np.all(s2[~tiles] == -7.0), route          # tiles strictly above the diagonal untouched
+	assert rel_err(outs[1][0][:, :n], outs[0][0][:, :n]) < 1e-14
+
+
 @pytest.mark.parametrize("use_ws", [False, True])
 def test_gram_cols_combine_diag_lower(L, use_ws):
 	rng = np.random.RandomState(3)

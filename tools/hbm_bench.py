@@ -61,9 +61,15 @@ if "gram" in what:
 	ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, d)), dtype=torch.uint8, device=dev)
 	for kind, name in ((0, "SE"), (3, "Matern52")):
 		for lower in (1, 0):
-			t = timed(lambda: L.check(lib.stpy_gram(kind, L.F64, L.ptr(x), n, d, L.ptr(x), n, d, d, None, L.ptr(il), 1.0, 0.0, 0.01, lower, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()), "gram"))
+			res = []
+			for route in (1, 0):          # route key 28: the dedicated fill kernel / the GEMM epilogue
+				lib.stpy_tune(28, route)
+				t = timed(lambda: L.check(lib.stpy_gram(kind, L.F64, L.ptr(x), n, d, L.ptr(x), n, d, d, None, L.ptr(il), 1.0, 0.0, 0.01, lower, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()), "gram"))
+				res.append(t)
+			lib.stpy_tune(28, 1)
 			tiles = (n // 128) * (n // 128 + 1) // 2 if lower else (n // 128) ** 2
-			print("gram %s %s N=%d: %.3f ms = %.2f TB/s of tile bytes" % (name, "lower" if lower else "full ", n, t * 1e3, tiles * 128 * 128 * 8 / t / 1e12), flush=True)
+			by = tiles * 128 * 128 * 8
+			print("gram %s %s N=%d: dedicated %.3f ms = %.2f TB/s | GEMM epilogue %.3f ms = %.2f TB/s" % (name, "lower" if lower else "full ", n, res[0] * 1e3, by / res[0] / 1e12, res[1] * 1e3, by / res[1] / 1e12), flush=True)
 	del K
 
 if "rff" in what:
