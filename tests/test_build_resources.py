@@ -176,3 +176,25 @@ def test_bench_always_prints_one_json_line():
 	import torch
 	if not torch.cuda.is_available() or torch.cuda.device_count() < 8:
 		assert r.returncode != 0 and out["value"] is None and out["n_gpus"] == 8 and out["error"]
+
+
+def test_round3_kernels_keep_their_occupancy(tmp_path):
+	"""gemm_nt_bf3_kernel (fp32 on the bf16 matrix cores): two workgroups per CU -- <= 256 VGPRs with BOTH accumulator sets (the
+	two-level accumulation) in registers, no scratch, 48 KiB of LDS.  gram_fill_f64_kernel: the squared-exponential and linear forms
+	fit four workgroups per CU (<= 128 VGPRs, no scratch, <= 40 KiB of LDS); the Matern forms three."""
+	out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", os.path.join(CSRC, "gemm.hip"),
+						  "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True).stderr
+	blocks = {b.split()[0]: b for b in re.split(r"remark: Function Name: ", out)[1:]}
+	get = lambda b, key: int(re.search(key + r": (\d+)", b).group(1))
+	bf3 = [b for n, b in blocks.items() if "gemm_nt_bf3_kernel" in n]
+	assert len(bf3) == 3
+	for b in bf3:
+		assert get(b, r"\bVGPRs") <= 256 and get(b, r"ScratchSize \[bytes/lane\]") == 0 and get(b, r"Occupancy \[waves/SIMD\]") >= 2
+		assert get(b, r"LDS Size \[bytes/block\]") <= 48 * 1024
+	fills = {n: b for n, b in blocks.items() if "gram_fill_f64_kernel" in n}
+	assert len(fills) == 4
+	for n, b in fills.items():
+		fast = "ILi0E" in n or "ILi4E" in n          # STPY_K_SE = 0, STPY_K_LINEAR = 4
+		assert get(b, r"Occupancy \[waves/SIMD\]") >= (4 if fast else 3), n
+		assert get(b, r"ScratchSize \[bytes/lane\]") == 0, n
+		assert get(b, r"LDS Size \[bytes/block\]") <= 40 * 1024, n
