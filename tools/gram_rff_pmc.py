@@ -26,7 +26,7 @@ def main():
 	res = {"_what": "rocprofv3 --kernel-trace --stats and three --pmc passes (WRITE_SIZE; FETCH_SIZE; SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES "
 					"SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -- separate runs, no tracing options) over `python3 tools/gram_rff_only.py`; counter values of the last "
 					"launch of each kernel; WRITE_SIZE / FETCH_SIZE in KB as rocprofv3 prints them, converted to bytes here"}
-	for tag, sub, alg_out in (("gram_fill", "gemm_nt_kernel<double, false, 0, 3>", 131328 * 128 * 128 * 8.0),
+	for tag, sub, alg_out in (("gram_fill", "gram_fill_f64_kernel", 131328 * 128 * 128 * 8.0),
 							  ("rff_stream_bf16x3", "rff_stream_bf16x3_kernel", 262144.0 * 32768 * 4)):
 		e = {"kernel": sub, "algorithmic_bytes_out": alg_out}
 		ks = kernel_ms(os.path.join(d, "gr_kt", "gr_kernel_stats.csv"), sub)
