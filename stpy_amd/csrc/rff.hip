@@ -471,6 +471,10 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 
 	for (int rb = blockIdx.x >> 3; rb < row_blocks; rb += gridDim.x >> 3) {
 		const int64_t row0 = (int64_t)rb * 128 + wm * 64;
+		// every row block starts its sweep over the column part at a different tile: the 64 workgroups of an XCD then write 32 different
+		// column positions at any moment instead of marching through the same one (rows are a power of two apart: tools/ld_pad_probe.py)
+		const int rot = (2 * rb) % tiles;
+		auto ct = [&](int j) { const int t = j + rot; return t >= tiles ? t - tiles : t; };
 		bf8 a[3][4][2];                                   // [part][row tile][K half]: the wave's 64 rows, resident for the sweep
 #pragma unroll
 		for (int tm = 0; tm < 4; ++tm)
@@ -487,7 +491,7 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 		bf8 b[3][2][2];                                   // [part][column tile][K half]: ONE buffer; a part is re-loaded for the next tile
 		auto load_b = [&](int p, int j) {                  // as soon as the products that read it have been issued
 			if constexpr ((exp & 4) != 0) { if (j > 1) return; }
-			const char* const wb = (const char*)(ws + (int64_t)((colp + (2 * j + wn) * 32) >> 4) * (2 * 3 * 64));          // uniform
+			const char* const wb = (const char*)(ws + (int64_t)((colp + (2 * ct(j) + wn) * 32) >> 4) * (2 * 3 * 64));          // uniform
 #pragma unroll
 			for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -504,10 +508,10 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 			float off[2];                                       // the accumulation starts from the column's phase offset (b / 2pi; -1/4 turns cos into sin)
 #pragma unroll
 			for (int tn = 0; tn < 2; ++tn) {
-				const int col = colp + (2 * j + wn) * 32 + tn * 16 + r16;
+				const int col = colp + (2 * ct(j) + wn) * 32 + tn * 16 + r16;
 				off[tn] = bias ? bias[col] * INV_2PI : (col < half ? 0.f : -0.25f);
 			}
-			float* const ob = out + row0 * ldo + (colp + (2 * (j - 2) + wn) * 32);             // uniform: tile j-2's first element
+			float* const ob = out + row0 * ldo + (colp + (2 * ct(j >= 2 ? j - 2 : j) + wn) * 32);             // uniform: tile j-2's first element (unused while j < 2)
 			v4f fv;
 			float tf[2], tc[2];
 #pragma unroll
@@ -559,7 +563,7 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 		};
 		auto flush = [&](int j, const float* cwf) {                     // ... and the last two tiles' stores
 			if constexpr ((exp & 1) != 0) { if (scale != 12345.f) return; }
-			float* const ob = out + row0 * ldo + (colp + (2 * j + wn) * 32);             // uniform
+			float* const ob = out + row0 * ldo + (colp + (2 * ct(j) + wn) * 32);             // uniform
 #pragma unroll
 			for (int q = 0; q < 8; ++q) {
 				const v4f v = *(const v4f*)&cwf[ld_lane + (unsigned)(8 * q * CLD)];
