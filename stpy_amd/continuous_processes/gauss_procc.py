@@ -163,8 +163,17 @@ class GaussianProcess(Estimator):
 		_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(K.dtype), n, n, St.shape[1], _lib.ptr(nSt), nSt.stride(0), _lib.ptr(St), St.stride(0),
 									_lib.ptr(K), K.stride(0), 1, 0, _lib.stream_ptr()), "stpy_gemm_nt")
 
-	def _factor(self, xd, kwargs=None, Sigma=None):
-		"""K_theta = k(x,x) + s^2 I (or + Sigma^T Sigma) -> in-place Cholesky.  Returns (L, winv)."""
+	@staticmethod
+	def _check_info(info):
+		"""The one synchronisation of a fit: the factorisation's status word (first failing pivot, 1-based; 0 = fine)."""
+		bad = int(info.item())
+		if bad != 0:
+			raise torch.linalg.LinAlgError("stpy_potrf: the leading minor of order %d of K + s^2 I is not positive definite" % bad)
+
+	def _factor(self, xd, kwargs=None, Sigma=None, defer_check=False):
+		"""K_theta = k(x,x) + s^2 I (or + Sigma^T Sigma) -> in-place Cholesky.  Returns (L, winv); with ``defer_check`` also the
+		device status word, unread -- the caller enqueues what follows the factorisation first and then calls ``_check_info``,
+		so the device does not idle through the host round trip."""
 		lib = _lib.load()
 		n0 = xd.shape[0]
 		n = _tile_pad(n0)
@@ -191,10 +200,10 @@ class GaussianProcess(Estimator):
 		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
 		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr())
 		_lib.check(rc, "stpy_potrf")
-		bad = int(info.item())          # the one synchronisation of a fit
 		del work
-		if bad != 0:
-			raise torch.linalg.LinAlgError("stpy_potrf: the leading minor of order %d of K + s^2 I is not positive definite" % bad)
+		if defer_check:
+			return K, winv, info
+		self._check_info(info)
 		return K, winv
 
 	def _forward_y(self, L, winv, yd):
@@ -244,11 +253,15 @@ class GaussianProcess(Estimator):
 		# object that takes the prior branch instead of one that reports fitted=True with no factor behind it
 		self.fitted = False
 		self._L = self._winv = self._z = self._alpha_cache = None       # release the previous factor before allocating the next
-		self._L, self._winv = self._factor(self._xd, None, Sigma)
-		self._z = self._forward_y(self._L, self._winv, self._yd)
+		L, winv, info = self._factor(self._xd, None, Sigma, defer_check=True)
+		z = self._forward_y(L, winv, self._yd)
 		# A = K^-1 y is part of the fitted state the reference leaves behind (gauss_procc.py:376): computed
 		# eagerly even though mean_std itself only needs z
-		self._alpha_cache = self._backward_z(self._L, self._winv, self._z)[:self.n]
+		alpha = self._backward_z(L, winv, z)[:self.n]
+		# the two vector solves are already queued behind the factorisation when the host reads its status (on a matrix that is
+		# not positive definite they ran on garbage and are dropped with the exception: the object stays unfitted)
+		self._check_info(info)
+		self._L, self._winv, self._z, self._alpha_cache = L, winv, z, alpha
 		self._factor_key = self._hyper_key(self.kernel_object)
 		self.fitted = True
 		return None

@@ -464,7 +464,12 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 	const int part = blockIdx.x & 7;
 	const int tiles = cols_per_part / 64;                 // 32-column tiles per wave and row block (the two wn waves alternate)
 	const int colp = part * cols_per_part;
-	const unsigned o_lane = (unsigned)rr * (unsigned)ldo + (unsigned)c4;   // lane part of an output address
+	const unsigned o_lane = ((unsigned)rr * (unsigned)ldo + (unsigned)c4) * 4u;   // lane part of an output address, in bytes (ldo < 2^26: the launcher)
+	// non-temporal 16-byte store at SGPR base + 32-bit lane offset (written out: through a pointer expression hipcc keeps the zero-extended
+	// lane offset as a 64-bit register pair and adds the base on the vector ALU for every store -- two more VGPRs than this kernel has)
+	// (s_nop 1: a store of more than 8 bytes reads its data registers for a couple of cycles after issue, and the instruction behind
+	// an asm statement may already overwrite them -- the wait states hipcc inserts by itself behind a store it knows)
+	auto store_nt = [&](const float* ubase, v4f v) { asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" :: "v"(o_lane), "v"(v), "s"(ubase) : "memory"); };
 	const unsigned st_lane = (unsigned)(4 * kq) * CLD + r16;               // lane part of a staging write
 	const unsigned ld_lane = (unsigned)rr * CLD + c4;                      // lane part of a staging read
 	const unsigned b_lane = (unsigned)lane * 16u;                          // lane part (bytes) of a W fragment address
@@ -526,7 +531,7 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 							acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[AP[grp]][tm][kh], b[BP[grp]][tn][kh], (grp == 0 && kh == 0) ? v4f{off[tn], off[tn], off[tn], off[tn]} : acc[tm][tn], 0, 0, 0);
 							if constexpr (FLUSH) {
 								if (idx % 12 == 1 && !(exp & 1)) fv = *(const v4f*)&cwf[ld_lane + (unsigned)(8 * (idx / 12) * CLD)];
-								if (idx % 12 == 10 && !(exp & 1)) __builtin_nontemporal_store(fv, (v4f*)((ob + (int64_t)(8 * (idx / 12)) * ldo) + o_lane));
+								if (idx % 12 == 10 && !(exp & 1)) store_nt(ob + (int64_t)(8 * (idx / 12)) * ldo, fv);
 							}
 							if (idx % 3 == 2) {
 								// the trig chain of an element (v_fract -> v_cos -> v_mul -> ds_write) as a three-stage pipeline over the
@@ -567,7 +572,7 @@ void rff_stream_bf16x3_kernel(const float* __restrict__ x, int64_t ldx, const u4
 #pragma unroll
 			for (int q = 0; q < 8; ++q) {
 				const v4f v = *(const v4f*)&cwf[ld_lane + (unsigned)(8 * q * CLD)];
-				__builtin_nontemporal_store(v, (v4f*)((ob + (int64_t)(8 * q) * ldo) + o_lane));
+				store_nt(ob + (int64_t)(8 * q) * ldo, v);
 				if (q == 3) __builtin_amdgcn_sched_barrier(0);          // two batches of four: 16 transient VGPRs, not 32 (the kernel sits at the 256 limit)
 			}
 		};
@@ -619,7 +624,7 @@ int rff_embed<float>(const float* x, int64_t n, int64_t ldx, int d, const float*
 		if (wgs > 8 * row_blocks) wgs = 8 * row_blocks;
 		// with a workspace: the contraction on the bf16 matrix cores from an exact three-way split of both operands (stpy_tune key 9 = 5
 		// keeps the fp32-MFMA kernel for A/B runs)
-		if (work && work_bytes >= rff_workspace_bytes(4, n, d, m) && g_rff_tile == 1 && (((uintptr_t)work) & 15) == 0 && m * 6 * 64 < ((int64_t)1 << 31)) {
+		if (work && work_bytes >= rff_workspace_bytes(4, n, d, m) && g_rff_tile == 1 && (((uintptr_t)work) & 15) == 0 && m * 6 * 64 < ((int64_t)1 << 31) && ldo < ((int64_t)1 << 26)) {
 			const int64_t blocks = (m / 16) * 2;
 			hipLaunchKernelGGL(rff_split_w_kernel, dim3((unsigned)((blocks * 64 + 255) / 256)), dim3(256), 0, st, W, ldw, blocks, (u4v*)work);
 			int rc = check_launch("rff_split_w");
