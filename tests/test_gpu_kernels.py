@@ -894,6 +894,28 @@ def test_rff_f32_bf16_split_kernel_strided(L):
 	assert np.abs(got[:, :m]).max() <= scale * (1 + 1e-6)
 
 
+def test_rff_f32_bf16_split_kernel_rotated_sweep(L):
+	"""every row block starts its sweep over the column part at tile 2 rb mod tiles and wraps around: a tile count per part that is
+	not a power of two (m = 3072: six tiles), more row blocks than tiles, every element written exactly once and right"""
+	lib = L.load()
+	n, d, m = 8192 + 5 * 128, 64, 3072
+	rng = np.random.RandomState(23)
+	x = rng.uniform(-1, 1, size=(n, d)).astype(np.float32)
+	W = (rng.normal(size=(m, d)) / 3.0).astype(np.float32)
+	xd, Wd = dev(x, torch.float32), dev(W, torch.float32)
+	wb = int(lib.stpy_rff_workspace_bytes(L.F32, n, d, m))
+	assert wb > 0
+	work = torch.empty(wb, dtype=torch.uint8, device="cuda:0")
+	out = torch.full((n, m), 7.0, dtype=torch.float32, device="cuda:0")
+	scale = float(np.sqrt(2.0 / m))
+	L.check(lib.stpy_rff_embed(L.F32, L.ptr(xd), n, d, d, L.ptr(Wd), d, m, None, None, scale, L.ptr(out), m, 0, L.ptr(work), wb, L.stream_ptr()), "rff")
+	got = out.cpu().numpy()
+	assert np.abs(got).max() <= scale * (1 + 1e-6)          # the fill value is gone everywhere
+	rows = np.r_[0:128, 128 * 3:128 * 4, 128 * 37:128 * 38, n - 128:n]          # row blocks 0, 3, 37 and the last: four different rotations
+	ref = O.rff_embed(x[rows].astype(np.float64), W.astype(np.float64), m)
+	assert np.abs(got[rows] - ref).max() < 2e-5 * scale
+
+
 def test_rff_f32_streaming_kernel(L):
 	"""n >= 8192, m % 1024 == 0, d = 64: the persistent streaming kernel (stpy_tune key 9 = 1) against the tile kernel (2) and
 	the GEMM epilogue (0), plain and biased, with a row count that leaves the last stride of row blocks partly idle"""
