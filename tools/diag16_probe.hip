@@ -1,0 +1,177 @@
+// The serial part of the diagonal-block kernel (potrf.hip: potf2_trtri_mfma_kernel::diag_block): Cholesky factor + inverse of a
+// 16 x 16 fp64 block in ONE wave, lane (q, i) = row i, columns 4q .. 4q+3.  Variant 0: the shipped form (nine LDS lane permutes of
+// a double per pivot).  Variant 1: the pivot row of the inverse through DPP row broadcasts, the column multiplier through
+// v_permlane16_swap / v_permlane32_swap row broadcasts, the next pivot taken from its own one-FMA update (no permute on the chain).
+// Prints cycles per block and the largest error against a host factorisation.
+// build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef double T;
+__device__ __forceinline__ double bcast(double v, int src)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+	return __hiloint2double(hi, lo);
+}
+// all four 16-lane rows <- row R of x
+template <int R>
+__device__ __forceinline__ unsigned row_bcast_u(unsigned x)
+{
+	auto t = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+	const unsigned h = t[R & 1];
+	auto u = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+	return u[R >> 1];
+}
+template <int R>
+__device__ __forceinline__ double row_bcast(double v)
+{
+	return __hiloint2double((int)row_bcast_u<R>((unsigned)__double2hiint(v)), (int)row_bcast_u<R>((unsigned)__double2loint(v)));
+}
+// every lane <- lane J of its own 16-lane row (DPP row_newbcast)
+template <int J>
+__device__ __forceinline__ double lane_bcast(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+template <int VAR, int J>
+__device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int i, int lane, int& first_bad)
+{
+	constexpr int qj = J >> 2, cj = J & 3;
+	T d = ((VAR & 1) && J > 0) ? bcast(dnext, 16 * qj + J) : bcast(a[cj], 16 * qj + J);
+	if (VAR & 2) asm volatile("" : "+v"(d));          // opaque: hipcc otherwise keeps the whole uniform chain (rsqrt, Newton steps) in SGPRs, one v_readfirstlane pair per VALU result
+	const bool bad = !(d > T(0)) || !(d < T(1e300));
+	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
+	d = bad ? T(1) : d;
+	T rl = (T)__builtin_amdgcn_rsq(d);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	const T l = d * rl;
+	const T colv = (i == J) ? l : a[cj] * rl;
+	a[cj] = (q == qj && i >= J) ? colv : a[cj];
+	T mi, lk[4], wj[4];
+	if (!(VAR & 1)) {
+		mi = __shfl(colv, 16 * qj + i, 64);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { lk[c] = __shfl(colv, 16 * qj + 4 * q + c, 64); wj[c] = __shfl(w[c], 16 * q + J, 64); }
+	} else {
+		mi = row_bcast<qj>(colv);
+		if (J + 1 < 16) {          // the next pivot's diagonal element, by the same FMA the update below applies to it (l_kj = l_ij on the diagonal)
+			constexpr int cn = (J + 1) & 3;
+			dnext = a[cn] - mi * mi;
+		}
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { lk[c] = __shfl(mi, 16 * q + 4 * q + c, 64); wj[c] = lane_bcast<J>(w[c]); }
+	}
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const int k = 4 * q + c;
+		const T na = a[c] - mi * lk[c];
+		a[c] = (k > J && i >= k) ? na : a[c];
+		const T ws = wj[c] * rl;
+		const T nw = w[c] - mi * ws;
+		w[c] = (i == J) ? ws : ((i > J) ? nw : w[c]);
+	}
+}
+
+template <int VAR>
+__global__ __launch_bounds__(64) void diag_kernel(const T* __restrict__ in, T* __restrict__ outL, T* __restrict__ outW, int nblk, int reps, long long* cycles)
+{
+	extern __shared__ T S[];          // nblk blocks of 16 x 16
+	const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+	for (int t = lane; t < nblk * 256; t += 64) S[t] = in[t];
+	__syncthreads();
+	long long t0 = 0;
+	for (int r = 0; r <= reps; ++r) {
+		if (r == 1) t0 = __builtin_amdgcn_s_memtime();          // repetition 0 warms the instruction cache
+		for (int b = 0; b < nblk; ++b) {
+			T a[4], w[4], dnext = 0;
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				a[c] = (col <= i) ? S[b * 256 + i * 16 + col] : T(0);
+				w[c] = (col == i) ? T(1) : T(0);
+			}
+			int first_bad = 0;
+			pivot<VAR, 0>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 1>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 2>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 3>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 4>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 5>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 6>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 7>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 8>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 9>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 10>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 11>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 12>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 13>(a, w, dnext, q, i, lane, first_bad);
+			pivot<VAR, 14>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 15>(a, w, dnext, q, i, lane, first_bad);
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				outL[b * 256 + i * 16 + col] = (col <= i) ? a[c] : T(0);
+				outW[b * 256 + i * 16 + col] = (col <= i) ? w[c] : T(0);
+			}
+			if (first_bad) outL[0] = -1;
+		}
+	}
+	if (lane == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
+}
+
+__global__ void perm_check(unsigned* o)
+{
+	const unsigned x = threadIdx.x;
+	o[threadIdx.x] = row_bcast_u<0>(x);
+	o[64 + threadIdx.x] = row_bcast_u<1>(x);
+	o[128 + threadIdx.x] = row_bcast_u<2>(x);
+	o[192 + threadIdx.x] = row_bcast_u<3>(x);
+	o[256 + threadIdx.x] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + 5, 0xf, 0xf, false);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main()
+{
+	unsigned* po; CK(hipMalloc(&po, 320 * 4));
+	hipLaunchKernelGGL(perm_check, dim3(1), dim3(64), 0, 0, po);
+	std::vector<unsigned> ph(320); CK(hipMemcpy(ph.data(), po, 320 * 4, hipMemcpyDeviceToHost));
+	bool ok = true;
+	for (int r = 0; r < 4; ++r) for (int l = 0; l < 64; ++l) ok = ok && ph[r * 64 + l] == (unsigned)(16 * r + (l & 15));
+	for (int l = 0; l < 64; ++l) ok = ok && ph[256 + l] == (unsigned)((l & ~15) + 5);
+	printf("row_bcast (permlane16_swap + permlane32_swap) and row_newbcast DPP: %s\n", ok ? "as assumed" : "NOT as assumed");
+	if (!ok) { for (int r = 0; r < 5; ++r) { for (int l = 0; l < 64; ++l) printf("%u ", ph[r * 64 + l]); printf("\n"); } }
+
+	const int nblk = 8, reps = 200;
+	std::vector<double> A(nblk * 256), Lr(nblk * 256), Wr(nblk * 256);
+	srand(5);
+	for (int b = 0; b < nblk; ++b) {
+		double G[16][16];
+		for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) G[i][j] = (rand() / (double)RAND_MAX) - 0.5;
+		for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = (i == j) ? 0.5 : 0.0; for (int k = 0; k < 16; ++k) s += G[i][k] * G[j][k]; A[b * 256 + i * 16 + j] = s; }
+		// host Cholesky + inverse
+		double Lh[16][16] = {}, Wh[16][16] = {};
+		for (int j = 0; j < 16; ++j) {
+			double s = A[b * 256 + j * 16 + j]; for (int k = 0; k < j; ++k) s -= Lh[j][k] * Lh[j][k];
+			Lh[j][j] = sqrt(s);
+			for (int i = j + 1; i < 16; ++i) { double t = A[b * 256 + i * 16 + j]; for (int k = 0; k < j; ++k) t -= Lh[i][k] * Lh[j][k]; Lh[i][j] = t / Lh[j][j]; }
+		}
+		for (int j = 0; j < 16; ++j) { Wh[j][j] = 1.0 / Lh[j][j]; for (int i = j + 1; i < 16; ++i) { double t = 0; for (int k = j; k < i; ++k) t += Lh[i][k] * Wh[k][j]; Wh[i][j] = -t / Lh[i][i]; } }
+		for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { Lr[b * 256 + i * 16 + j] = Lh[i][j]; Wr[b * 256 + i * 16 + j] = Wh[i][j]; }
+	}
+	double *din, *dL, *dW; long long* dc;
+	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 8));
+	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
+	for (int var = 0; var < 4; ++var) {
+		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_kernel<3>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		CK(hipDeviceSynchronize());
+		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
+		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
+		double eL = 0, eW = 0;
+		for (size_t t = 0; t < A.size(); ++t) { eL = fmax(eL, fabs(Lg[t] - Lr[t])); eW = fmax(eW, fabs(Wg[t] - Wr[t])); }
+		printf("variant %d: %.0f memtime ticks per 16x16 block (at 2.4 GHz: %.2f us), max |L - L_host| %.2e, max |W - W_host| %.2e\n", var, (double)cyc / (reps * nblk), (double)cyc / (reps * nblk) / 2400.0, eL, eW);
+	}
+	return 0;
+}
