@@ -1,0 +1,96 @@
+"""Randomised parity sweep through the drop-in classes against the CPU oracle (checker only): random sizes (ragged, tiny, around the
+128 / 512 / 1024 tile and panel edges), dimensions, kernel families and hyper-parameters; fit_gp + mean_std (+ full covariance) +
+log_marginal + add_data_point, in fp64 with the 1e-8 bar of SURVEY.md section 8d scaled by the conditioning of the case.
+usage: python tools/fuzz_parity.py [cases] [seed]         exit code 1 on the first failure (the failing case is printed)"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from oracle import gp_oracle as O          # checker only
+from stpy_amd import GaussianProcess, KernelFunction
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.RandomState(seed)
+dev = torch.device("cuda:0")
+SIZES = [1, 2, 3, 5, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 383, 511, 512, 513, 640, 700, 1023, 1024, 1025, 1300, 2047, 2048, 2100, 3000]
+
+
+def rel(a, b):
+	nb = np.linalg.norm(b)
+	return float(np.linalg.norm(a - b) / (nb if nb > 0 else 1.0))
+
+
+t_start = time.time()
+worst = 0.0
+for case in range(cases):
+	n = int(rng.choice(SIZES)) if rng.uniform() < 0.8 else int(rng.randint(1, 1500))
+	d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33]))
+	m = int(rng.choice([1, 2, 7, 64, 129, 300, 1000]))
+	fam = rng.choice(["squared_exponential", "ard", "matern", "ard_matern", "linear", "polynomial", "sum", "product"])
+	s = float(10.0 ** rng.uniform(-2, 0))
+	kappa = float(rng.uniform(0.5, 3.0))
+	gamma = float(np.sqrt(d) * rng.uniform(0.5, 2.0))
+	nu = float(rng.choice([0.5, 1.5, 2.5]))
+	ardg = (np.sqrt(d) * rng.uniform(0.5, 2.0, size=d)).astype(np.float64)
+	if d == 1:          # kernels.py:36-39: torch.Tensor([ard_gamma]) succeeds for a one-element tensor and rounds it to fp32 (the drop-in does the same)
+		ardg = ardg.astype(np.float32).astype(np.float64)
+	x = rng.uniform(-1, 1, size=(n, d))
+	y = np.sin(x.sum(1, keepdims=True)) + 0.1 * rng.normal(size=(n, 1))
+	xt = rng.uniform(-1, 1, size=(m, d))
+	if fam == "squared_exponential":
+		ko = KernelFunction(kernel_name=fam, gamma=gamma, kappa=kappa, d=d); spec = [(fam, {"gamma": gamma, "kappa": kappa}, "-")]
+	elif fam == "ard":
+		ko = KernelFunction(kernel_name=fam, ard_gamma=torch.from_numpy(ardg), kappa=kappa, d=d); spec = [(fam, {"ard_gamma": ardg, "kappa": kappa}, "-")]
+	elif fam == "matern":
+		ko = KernelFunction(kernel_name=fam, gamma=gamma, nu=nu, kappa=kappa, d=d); spec = [(fam, {"gamma": gamma, "nu": nu, "kappa": kappa}, "-")]
+	elif fam == "ard_matern":
+		ko = KernelFunction(kernel_name=fam, ard_gamma=torch.from_numpy(ardg), nu=nu, kappa=kappa, d=d); spec = [(fam, {"ard_gamma": ardg, "nu": nu, "kappa": kappa}, "-")]
+	elif fam == "linear":
+		ko = KernelFunction(kernel_name=fam, kappa=kappa, d=d); spec = [(fam, {"kappa": kappa}, "-")]
+	elif fam == "polynomial":
+		ko = KernelFunction(kernel_name=fam, kappa=kappa, power=2, d=d); spec = [(fam, {"kappa": kappa, "degree": 2}, "-")]
+	else:
+		k1 = KernelFunction(kernel_name="squared_exponential", gamma=gamma, kappa=kappa, d=d)
+		k2 = KernelFunction(kernel_name="matern", gamma=1.5 * gamma, nu=nu, kappa=1.0, d=d)
+		ko = (k1 + k2) if fam == "sum" else (k1 * k2)
+		spec = [("squared_exponential", {"gamma": gamma, "kappa": kappa}, "-"), ("matern", {"gamma": 1.5 * gamma, "nu": nu, "kappa": 1.0}, "+" if fam == "sum" else "*")]
+	desc = "case %d: n=%d d=%d m=%d %s s=%.3g kappa=%.3g gamma=%.3g nu=%.1f" % (case, n, d, m, fam, s, kappa, gamma, nu)
+	try:
+		Ko = O.gram_train(x, spec, s)
+		cond = np.linalg.cond(Ko) if n <= 1500 else 1e6
+		tol = max(1e-8, 1e-13 * cond)
+		L, alpha = O.fit(x, y, spec, s)
+		mu_o, sd_o = O.mean_std(x, L, alpha, xt, spec)
+		lml_o = float(O.log_marginal(x, y, spec, s)[0, 0])
+		gp = GaussianProcess(kernel=ko, s=s, d=d)
+		xd, yd, xtd = (torch.from_numpy(v).to(dev) for v in (x, y, xt))
+		gp.fit_gp(xd, yd)
+		mu, sd = gp.mean_std(xtd)
+		lml = float(gp.log_marginal(gp.kernel_object, {}, 1.0).item())
+		e = [rel(mu.cpu().numpy(), mu_o), rel(sd.cpu().numpy(), sd_o), abs(lml - lml_o) / max(1.0, abs(lml_o))]
+		# the posterior std cancels (k** - ...): its error scales with kappa / sigma_min
+		sd_floor = float(np.abs(sd_o).min())
+		tol_sd = tol * max(1.0, kappa / max(sd_floor, 1e-300)) if sd_floor > 0 else np.inf
+		assert mu.shape == (m, 1) and sd.shape == (m, 1), (mu.shape, sd.shape)
+		assert e[0] < tol and e[1] < tol_sd and e[2] < tol, (e, tol, tol_sd)
+		if m <= 129:
+			mu2, cov = gp.mean_std(xtd, full=True)
+			_, cov_o = O.mean_cov(x, L, alpha, xt, spec)
+			assert rel(cov.cpu().numpy(), cov_o) < max(tol, tol_sd), ("full covariance", rel(cov.cpu().numpy(), cov_o))
+		if case % 5 == 0 and n >= 2:          # incremental data: drop the last point, fit, add it back (gauss_procc.py:100-111)
+			gp2 = GaussianProcess(kernel=ko, s=s, d=d)
+			gp2.fit_gp(xd[:-1], yd[:-1])
+			gp2.add_data_point(xd[-1:], yd[-1:])
+			mu3, sd3 = gp2.mean_std(xtd)
+			assert rel(mu3.cpu().numpy(), mu_o) < tol and rel(sd3.cpu().numpy(), sd_o) < tol_sd, ("add_data_point", rel(mu3.cpu().numpy(), mu_o))
+		worst = max(worst, e[0] / tol, e[2] / tol)
+	except Exception as ex:          # noqa: BLE001
+		print("FAILED", desc, "->", type(ex).__name__, ex, flush=True)
+		sys.exit(1)
+	if case % 20 == 0:
+		print("ok", desc, "cond %.1e  err mu %.1e sd %.1e lml %.1e" % (cond, e[0], e[1], e[2]), flush=True)
+print("all %d cases passed in %.0f s; worst error / tolerance %.2f" % (cases, time.time() - t_start, worst))
