@@ -1,6 +1,6 @@
 """Randomised parity sweep (tools/fuzz_parity.py) as part of the GPU suite: 80 random (size, dimension, kernel family, hyper-parameter)
 cases through the drop-in classes against the CPU oracle -- ragged and tiny sizes, tile / panel edges, sums and products of kernels,
-full covariance, add_data_point."""
+full covariance, add_data_point; then 40 random RFF embeds (both types, biased and plain, every kernel route)."""
 import os
 import subprocess
 import sys
@@ -12,6 +12,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_random_parity_sweep():
-	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "11"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "11", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
 	assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-	assert "all 80 cases passed" in r.stdout
+	assert "all 80 cases passed" in r.stdout and "all 40 rff cases passed" in r.stdout

@@ -1,7 +1,7 @@
 """Randomised parity sweep through the drop-in classes against the CPU oracle (checker only): random sizes (ragged, tiny, around the
 128 / 512 / 1024 tile and panel edges), dimensions, kernel families and hyper-parameters; fit_gp + mean_std (+ full covariance) +
 log_marginal + add_data_point, in fp64 with the 1e-8 bar of SURVEY.md section 8d scaled by the conditioning of the case.
-usage: python tools/fuzz_parity.py [cases] [seed]         exit code 1 on the first failure (the failing case is printed)"""
+usage: python tools/fuzz_parity.py [cases] [seed] [rff cases]        exit code 1 on the first failure (the failing case is printed)"""
 import sys
 import time
 
@@ -94,3 +94,41 @@ for case in range(cases):
 	if case % 20 == 0:
 		print("ok", desc, "cond %.1e  err mu %.1e sd %.1e lml %.1e" % (cond, e[0], e[1], e[2]), flush=True)
 print("all %d cases passed in %.0f s; worst error / tolerance %.2f" % (cases, time.time() - t_start, worst))
+
+# ---- RFF embed (embedding.py:225-241): every route of stpy_rff_embed is reached by some shape below -- the bf16-split streaming kernel
+# (fp32, d = 64, n >= 8192, m % 1024 == 0), the tile kernels (d = 32 / 64, n % 128 == 0, m % 64 == 0), the GEMM epilogue (everything
+# else), the fp64 GEMM + trig pass; plain and biased (the biased form comes back transposed, as in the reference)
+from stpy_amd import RFFEmbedding
+rcases = max(cases // 4, 8) if len(sys.argv) < 4 else int(sys.argv[3])
+for case in range(rcases):
+	dt = torch.float64 if rng.uniform() < 0.5 else torch.float32
+	n = int(rng.choice([1, 3, 33, 127, 128, 129, 640, 1000, 4096, 8192, 8192 + 384]))
+	d = int(rng.choice([1, 2, 5, 17, 32, 64]))
+	mm = int(rng.choice([2, 6, 64, 130, 192, 1024, 2048, 3072]))
+	biased = bool(rng.uniform() < 0.3)
+	gam = float(np.sqrt(d) * rng.uniform(0.7, 3.0))
+	kap = float(rng.uniform(0.5, 2.0))
+	desc = "rff case %d: %s n=%d d=%d m=%d biased=%s gamma=%.3g" % (case, str(dt)[6:], n, d, mm, biased, gam)
+	try:
+		emb = RFFEmbedding(gamma=gam, m=mm, d=d, kappa=kap, biased=biased)
+		emb.W = torch.from_numpy(rng.normal(size=(mm, d)) / gam)
+		if biased:
+			emb.b = torch.from_numpy(2 * np.pi * rng.uniform(size=mm))
+		xx = rng.uniform(-1, 1, size=(n, d))
+		xq = xx.astype(np.float32 if dt == torch.float32 else np.float64)
+		Wq = emb.W.numpy().astype(np.float32 if dt == torch.float32 else np.float64).astype(np.float64)
+		bq = None if not biased else emb.b.numpy().astype(np.float32 if dt == torch.float32 else np.float64).astype(np.float64)
+		z = emb.embed(torch.from_numpy(xq).to(dev)).cpu().numpy()
+		ref = O.rff_embed(xq.astype(np.float64), Wq, mm, kappa=kap, b=bq)
+		assert z.shape == ref.shape, (z.shape, ref.shape)
+		amp = np.sqrt(2.0 / mm) * np.sqrt(kap)
+		phase = float(np.abs(xq.astype(np.float64) @ Wq.T).max()) + (2 * np.pi if biased else 0.0)
+		tol = amp * (1e-13 * max(1.0, phase) if dt == torch.float64 else max(2e-5, 6e-6 * phase))
+		err = float(np.abs(z - ref).max())
+		assert err < tol, (err, tol)
+	except Exception as ex:          # noqa: BLE001
+		print("FAILED", desc, "->", type(ex).__name__, ex, flush=True)
+		sys.exit(1)
+	if case % 10 == 0:
+		print("ok", desc, "err / amplitude %.1e" % (err / amp), flush=True)
+print("all %d rff cases passed" % rcases)
