@@ -2,7 +2,8 @@
 // 16 x 16 fp64 block in ONE wave, lane (q, i) = row i, columns 4q .. 4q+3.  Variant 0: the shipped form (nine LDS lane permutes of
 // a double per pivot).  Variant 1: the pivot row of the inverse through DPP row broadcasts, the column multiplier through
 // v_permlane16_swap / v_permlane32_swap row broadcasts, the next pivot taken from its own one-FMA update (no permute on the chain).
-// Prints cycles per block and the largest error against a host factorisation.
+// Variants 2 / 3: the same with the pivot made opaque to hipcc's uniformity analysis.  Variant 4: factor and inverse on TWO waves.
+// Prints cycles per block and the largest error against a host factorisation.  (Measured: 8467 / 9031 / 8788 / 9183 / 10272.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -119,6 +120,94 @@ __global__ __launch_bounds__(64) void diag_kernel(const T* __restrict__ in, T* _
 	if (lane == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
+// ---- variant 4: TWO waves.  Wave 0 factors (the a-half of the pivot step), wave 1 builds the inverse (the w-half) one pivot behind:
+// per pivot wave 0 publishes the scaled column (the 16 values of row group qj) and 1/l_jj in LDS and then bumps a counter; wave 1
+// polls the counter (no barrier: both waves are resident in the same workgroup, and the LDS serves a wave's operations in order).
+struct Comm { double colv[16][16]; double rl[16]; int flag; };
+template <int J>
+__device__ __forceinline__ void pivot_factor(T (&a)[4], int q, int i, int lane, int& first_bad, Comm* cm, int seq0)
+{
+	constexpr int qj = J >> 2, cj = J & 3;
+	T d = bcast(a[cj], 16 * qj + J);
+	const bool bad = !(d > T(0)) || !(d < T(1e300));
+	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
+	d = bad ? T(1) : d;
+	T rl = (T)__builtin_amdgcn_rsq(d);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	const T l = d * rl;
+	const T colv = (i == J) ? l : a[cj] * rl;
+	a[cj] = (q == qj && i >= J) ? colv : a[cj];
+	if (q == qj) cm->colv[J][i] = colv;
+	if (lane == 0) cm->rl[J] = rl;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	if (lane == 0) __hip_atomic_store(&cm->flag, seq0 + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	const T mi = __shfl(colv, 16 * qj + i, 64);
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const T lk = __shfl(colv, 16 * qj + 4 * q + c, 64);
+		const int k = 4 * q + c;
+		const T na = a[c] - mi * lk;
+		a[c] = (k > J && i >= k) ? na : a[c];
+	}
+}
+template <int J>
+__device__ __forceinline__ void pivot_inverse(T (&w)[4], int q, int i, int lane, Comm* cm, int seq0)
+{
+	while (__hip_atomic_load(&cm->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq0 + J + 1) __builtin_amdgcn_s_sleep(1);
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	const T mi = cm->colv[J][i];
+	const T rl = cm->rl[J];
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const T wj = __shfl(w[c], 16 * q + J, 64);
+		const T ws = wj * rl;
+		const T nw = w[c] - mi * ws;
+		w[c] = (i == J) ? ws : ((i > J) ? nw : w[c]);
+	}
+}
+__global__ __launch_bounds__(128) void diag2_kernel(const T* __restrict__ in, T* __restrict__ outL, T* __restrict__ outW, int nblk, int reps, long long* cycles)
+{
+	extern __shared__ T S[];          // nblk blocks of 16 x 16, then the hand-over area
+	Comm* cm = reinterpret_cast<Comm*>(S + nblk * 256);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i = lane & 15;
+	for (int t = tid; t < nblk * 256; t += 128) S[t] = in[t];
+	if (tid == 0) cm->flag = 0;
+	__syncthreads();
+	long long t0 = 0;
+	int seq = 0;
+	for (int r = 0; r <= reps; ++r) {
+		if (r == 1) t0 = __builtin_amdgcn_s_memtime();
+		for (int b = 0; b < nblk; ++b, seq += 16) {
+			if (wave == 0) {
+				T a[4];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) { const int col = 4 * q + c; a[c] = (col <= i) ? S[b * 256 + i * 16 + col] : T(0); }
+				int first_bad = 0;
+				pivot_factor<0>(a, q, i, lane, first_bad, cm, seq); pivot_factor<1>(a, q, i, lane, first_bad, cm, seq); pivot_factor<2>(a, q, i, lane, first_bad, cm, seq); pivot_factor<3>(a, q, i, lane, first_bad, cm, seq);
+				pivot_factor<4>(a, q, i, lane, first_bad, cm, seq); pivot_factor<5>(a, q, i, lane, first_bad, cm, seq); pivot_factor<6>(a, q, i, lane, first_bad, cm, seq); pivot_factor<7>(a, q, i, lane, first_bad, cm, seq);
+				pivot_factor<8>(a, q, i, lane, first_bad, cm, seq); pivot_factor<9>(a, q, i, lane, first_bad, cm, seq); pivot_factor<10>(a, q, i, lane, first_bad, cm, seq); pivot_factor<11>(a, q, i, lane, first_bad, cm, seq);
+				pivot_factor<12>(a, q, i, lane, first_bad, cm, seq); pivot_factor<13>(a, q, i, lane, first_bad, cm, seq); pivot_factor<14>(a, q, i, lane, first_bad, cm, seq); pivot_factor<15>(a, q, i, lane, first_bad, cm, seq);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) { const int col = 4 * q + c; outL[b * 256 + i * 16 + col] = (col <= i) ? a[c] : T(0); }
+				if (first_bad) outL[0] = -1;
+			} else {
+				T w[4];
+#pragma unroll
+				for (int c = 0; c < 4; ++c) w[c] = (4 * q + c == i) ? T(1) : T(0);
+				pivot_inverse<0>(w, q, i, lane, cm, seq); pivot_inverse<1>(w, q, i, lane, cm, seq); pivot_inverse<2>(w, q, i, lane, cm, seq); pivot_inverse<3>(w, q, i, lane, cm, seq);
+				pivot_inverse<4>(w, q, i, lane, cm, seq); pivot_inverse<5>(w, q, i, lane, cm, seq); pivot_inverse<6>(w, q, i, lane, cm, seq); pivot_inverse<7>(w, q, i, lane, cm, seq);
+				pivot_inverse<8>(w, q, i, lane, cm, seq); pivot_inverse<9>(w, q, i, lane, cm, seq); pivot_inverse<10>(w, q, i, lane, cm, seq); pivot_inverse<11>(w, q, i, lane, cm, seq);
+				pivot_inverse<12>(w, q, i, lane, cm, seq); pivot_inverse<13>(w, q, i, lane, cm, seq); pivot_inverse<14>(w, q, i, lane, cm, seq); pivot_inverse<15>(w, q, i, lane, cm, seq);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) { const int col = 4 * q + c; outW[b * 256 + i * 16 + col] = (col <= i) ? w[c] : T(0); }
+			}
+			__syncthreads();          // (the real kernel has a workgroup barrier here as well: both halves are done before the panel below uses them)
+		}
+	}
+	if (tid == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
+}
+
 __global__ void perm_check(unsigned* o)
 {
 	const unsigned x = threadIdx.x;
@@ -161,11 +250,12 @@ int main()
 	double *din, *dL, *dW; long long* dc;
 	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 8));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 4; ++var) {
+	for (int var = 0; var < 5; ++var) {
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag_kernel<3>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 3) hipLaunchKernelGGL(diag_kernel<3>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag2_kernel, dim3(1), dim3(128), nblk * 256 * 8 + sizeof(Comm), 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
