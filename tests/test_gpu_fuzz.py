@@ -15,3 +15,21 @@ def test_random_parity_sweep():
 	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", "11", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
 	assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 	assert "all 80 cases passed" in r.stdout and "all 40 rff cases passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_random_gemm_sweep():
+	"""tools/fuzz_gemm.py: 150 random (m, n, k, leading dimensions, mode, lower-only, type) products through stpy_gemm_nt against fp64
+	matmul; NaN-poisoned operand padding, untouched output padding and untouched tiles above the diagonal"""
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gemm.py"), "150", "3"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+	assert "all 150 gemm cases passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_random_factor_solve_sweep():
+	"""tools/fuzz_factor.py: 60 random (order, right-hand sides, panel width, flags, padding, block-solve route, type) runs of
+	stpy_potrf -> stpy_trsm_right_lt -> stpy_trsv (both ways) -> stpy_logdet_quad against numpy / scipy"""
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_factor.py"), "60", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+	assert "all 60 factor / solve cases passed" in r.stdout

@@ -1,0 +1,60 @@
+"""Randomised check of stpy_gemm_nt through the C ABI: every dispatch route (direct-to-VGPR tiles, the guarded generic kernel for ragged
+shapes, K = 128 volley kernel, skinny-row kernel, fp32 products on the bf16 matrix cores, lower-only) is reached by some random
+(m, n, k, leading dimensions, mode, type) below.  Reference: torch fp64 matmul.  Padding of the leading dimensions is poisoned with NaN
+(must never be read) and the padding of C must keep its fill value (must never be written).
+usage: python tools/fuzz_gemm.py [cases] [seed]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from stpy_amd import _lib as L
+
+lib = L.load()
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+DIMS = [1, 2, 3, 7, 8, 9, 16, 31, 64, 100, 127, 128, 129, 255, 256, 384, 500, 512, 640, 1000, 1024, 1152, 2048, 2500]
+KS = [1, 2, 4, 7, 16, 32, 33, 64, 100, 128, 129, 256, 512, 1000, 1024, 2048]
+for case in range(cases):
+	dt = torch.float64 if rng.uniform() < 0.6 else torch.float32
+	m, n, k = int(rng.choice(DIMS)), int(rng.choice(DIMS)), int(rng.choice(KS))
+	mode = int(rng.choice([0, 1, 2]))
+	lower = int(rng.uniform() < 0.3)
+	if lower:
+		n = m
+	pa, pb, pc = (int(rng.choice([0, 0, 2, 4, 16, 36])) for _ in range(3))
+	desc = "case %d: %s m=%d n=%d k=%d mode=%d lower=%d pads %d/%d/%d" % (case, str(dt)[6:], m, n, k, mode, lower, pa, pb, pc)
+	A = torch.full((m, k + pa), float("nan"), dtype=dt, device=dev); A[:, :k] = torch.randn(m, k, dtype=dt, device=dev)
+	same = bool(lower and rng.uniform() < 0.5)
+	if same:
+		B = A; pb = pa
+	else:
+		B = torch.full((n, k + pb), float("nan"), dtype=dt, device=dev); B[:, :k] = torch.randn(n, k, dtype=dt, device=dev)
+	C = torch.full((m, n + pc), 7.0, dtype=dt, device=dev); C[:, :n] = torch.randn(m, n, dtype=dt, device=dev)
+	C0 = C.clone()
+	rc = lib.stpy_gemm_nt(L.dtype_code(dt), m, n, k, L.ptr(A), k + pa, L.ptr(B), k + pb, L.ptr(C), n + pc, mode, lower, L.stream_ptr())
+	try:
+		assert rc == 0, (rc, lib.stpy_last_error_string())
+		torch.cuda.synchronize()
+		P = A[:, :k].double() @ B[:, :k].double().T
+		ref = P if mode == 0 else (C0[:, :n].double() - P if mode == 1 else C0[:, :n].double() + P)
+		got = C[:, :n].double()
+		scale = (A[:, :k].double().abs() @ B[:, :k].double().abs().T) + C0[:, :n].double().abs() + 1e-300
+		err = ((got - ref).abs() / scale)
+		if lower:          # tiles strictly above the diagonal are left alone; everything on or below the diagonal tiles is computed
+			ti = torch.arange(m, device=dev) // 128
+			msk = ti[:, None] >= ti[None, :]
+			assert torch.equal(C[:, :n][~msk], C0[:, :n][~msk]), "a tile above the diagonal was written"
+			err = err[msk]
+		tol = 4e-15 if dt == torch.float64 else 3e-6
+		assert float(err.max()) < tol, (float(err.max()), tol)
+		if pc:
+			assert bool((C[:, n:] == 7.0).all()), "padding of C written"
+	except AssertionError as ex:
+		print("FAILED", desc, "->", ex, flush=True)
+		sys.exit(1)
+	if case % 25 == 0:
+		print("ok", desc, "max err / sum|a||b| %.1e" % float(err.max()), flush=True)
+print("all %d gemm cases passed" % cases)
