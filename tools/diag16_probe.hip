@@ -3,7 +3,7 @@
 // a double per pivot).  Variant 1: the pivot row of the inverse through DPP row broadcasts, the column multiplier through
 // v_permlane16_swap / v_permlane32_swap row broadcasts, the next pivot taken from its own one-FMA update (no permute on the chain).
 // Variants 2 / 3: the same with the pivot made opaque to hipcc's uniformity analysis.  Variant 4: factor and inverse on TWO waves.
-// Prints cycles per block and the largest error against a host factorisation.  (Measured: 8467 / 9031 / 8788 / 9183 / 10272.)
+// Prints cycles per block and the largest error against a host factorisation.  (Measured: 8467 / 9031 / 8788 / 9183 / 9100-9500 with the factor wave alone at 8500-8800; variants 5-7: one Newton step 8207, fp32 estimate 8413, both 8260.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -50,9 +50,9 @@ __device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int
 	const bool bad = !(d > T(0)) || !(d < T(1e300));
 	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
 	d = bad ? T(1) : d;
-	T rl = (T)__builtin_amdgcn_rsq(d);
+	T rl = (VAR & 8) ? (T)__builtin_amdgcn_rsqf((float)d) : (T)__builtin_amdgcn_rsq(d);          // bit 3: fp32 estimate
 	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
-	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	if (!(VAR & 4)) rl = rl * (T(1.5) - T(0.5) * d * rl * rl);          // bit 2: ONE Newton step
 	const T l = d * rl;
 	const T colv = (i == J) ? l : a[cj] * rl;
 	a[cj] = (q == qj && i >= J) ? colv : a[cj];
@@ -140,7 +140,9 @@ __device__ __forceinline__ void pivot_factor(T (&a)[4], int q, int i, int lane, 
 	a[cj] = (q == qj && i >= J) ? colv : a[cj];
 	if (q == qj) cm->colv[J][i] = colv;
 	if (lane == 0) cm->rl[J] = rl;
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	// (the LDS serves one wave's operations in order, so the data stores are performed before the counter store without waiting for
+	// them: a compiler-level fence is all that is needed -- a workgroup-scope release fence costs an s_waitcnt on the pivot chain)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	if (lane == 0) __hip_atomic_store(&cm->flag, seq0 + J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	const T mi = __shfl(colv, 16 * qj + i, 64);
 #pragma unroll
@@ -174,11 +176,12 @@ __global__ __launch_bounds__(128) void diag2_kernel(const T* __restrict__ in, T*
 	for (int t = tid; t < nblk * 256; t += 128) S[t] = in[t];
 	if (tid == 0) cm->flag = 0;
 	__syncthreads();
-	long long t0 = 0;
+	long long t0 = 0, busy = 0;
 	int seq = 0;
 	for (int r = 0; r <= reps; ++r) {
-		if (r == 1) t0 = __builtin_amdgcn_s_memtime();
+		if (r == 1) { t0 = __builtin_amdgcn_s_memtime(); busy = 0; }
 		for (int b = 0; b < nblk; ++b, seq += 16) {
+			const long long tb = __builtin_amdgcn_s_memtime();
 			if (wave == 0) {
 				T a[4];
 #pragma unroll
@@ -202,10 +205,12 @@ __global__ __launch_bounds__(128) void diag2_kernel(const T* __restrict__ in, T*
 #pragma unroll
 				for (int c = 0; c < 4; ++c) { const int col = 4 * q + c; outW[b * 256 + i * 16 + col] = (col <= i) ? w[c] : T(0); }
 			}
+			busy += (long long)__builtin_amdgcn_s_memtime() - tb;
 			__syncthreads();          // (the real kernel has a workgroup barrier here as well: both halves are done before the panel below uses them)
 		}
 	}
 	if (tid == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
+	if (lane == 0) cycles[1 + wave] = busy;          // per wave: time from the start of a block to the end of its own half
 }
 
 __global__ void perm_check(unsigned* o)
@@ -248,19 +253,23 @@ int main()
 		for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { Lr[b * 256 + i * 16 + j] = Lh[i][j]; Wr[b * 256 + i * 16 + j] = Wh[i][j]; }
 	}
 	double *din, *dL, *dW; long long* dc;
-	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 8));
+	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 24));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 5; ++var) {
+	for (int var = 0; var < 8; ++var) {
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 3) hipLaunchKernelGGL(diag_kernel<3>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag2_kernel, dim3(1), dim3(128), nblk * 256 * 8 + sizeof(Comm), 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 4) hipLaunchKernelGGL(diag2_kernel, dim3(1), dim3(128), nblk * 256 * 8 + sizeof(Comm), 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 5) hipLaunchKernelGGL(diag_kernel<4>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 6) hipLaunchKernelGGL(diag_kernel<8>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_kernel<12>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
 		double eL = 0, eW = 0;
 		for (size_t t = 0; t < A.size(); ++t) { eL = fmax(eL, fabs(Lg[t] - Lr[t])); eW = fmax(eW, fabs(Wg[t] - Wr[t])); }
+		if (var == 4) { long long pw[3]; CK(hipMemcpy(pw, dc, 24, hipMemcpyDeviceToHost)); printf("variant 4: factor wave %.0f, inverse wave %.0f ticks per block (start of block -> own half done)\n", (double)pw[1] / (reps * nblk), (double)pw[2] / (reps * nblk)); }
 		printf("variant %d: %.0f memtime ticks per 16x16 block (at 2.4 GHz: %.2f us), max |L - L_host| %.2e, max |W - W_host| %.2e\n", var, (double)cyc / (reps * nblk), (double)cyc / (reps * nblk) / 2400.0, eL, eW);
 	}
 	return 0;
