@@ -3,7 +3,8 @@
 // a double per pivot).  Variant 1: the pivot row of the inverse through DPP row broadcasts, the column multiplier through
 // v_permlane16_swap / v_permlane32_swap row broadcasts, the next pivot taken from its own one-FMA update (no permute on the chain).
 // Variants 2 / 3: the same with the pivot made opaque to hipcc's uniformity analysis.  Variant 4: factor and inverse on TWO waves.
-// Prints cycles per block and the largest error against a host factorisation.  (Measured: 8467 / 9031 / 8788 / 9183 / 9100-9500 with the factor wave alone at 8500-8800; variants 5-7: one Newton step 8207, fp32 estimate 8413, both 8260.)
+// Prints cycles per block and the largest error against a host factorisation.  (Measured: 8467 / 9031 / 8788 / 9183 / 9100-9500 with the factor wave alone at 8500-8800; variants 5-7: one Newton step 8207, fp32 estimate 8413, both 8260; 8: lane masks recomputed per pivot instead of hoisted + spilled 10741;
+// 9 / 10: the pivot broadcast kept in vector registers and no select on a failing pivot 9564 / 10038.  The shipped form is the fastest of the eleven.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -45,11 +46,19 @@ template <int VAR, int J>
 __device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int i, int lane, int& first_bad)
 {
 	constexpr int qj = J >> 2, cj = J & 3;
-	T d = ((VAR & 1) && J > 0) ? bcast(dnext, 16 * qj + J) : bcast(a[cj], 16 * qj + J);
+	// bit 4: the lane coordinates are made opaque per pivot, so that hipcc cannot hoist the 16 x 7 lane masks out of the block loop
+	// (they do not fit into the SGPR file and come back through v_readlane spills: .sgpr_spill_count 142 in the shipped kernel)
+	if (VAR & 16) asm volatile("" : "+v"(q), "+v"(i));
+	T d;
+	if (VAR & 32) {          // bit 5: the pivot never leaves the vector registers (DPP lane broadcast inside its row, then the row to all rows) ...
+		const T src = ((VAR & 1) && J > 0) ? dnext : a[cj];
+		d = row_bcast<qj>(lane_bcast<J>(src));
+	} else
+		d = ((VAR & 1) && J > 0) ? bcast(dnext, 16 * qj + J) : bcast(a[cj], 16 * qj + J);
 	if (VAR & 2) asm volatile("" : "+v"(d));          // opaque: hipcc otherwise keeps the whole uniform chain (rsqrt, Newton steps) in SGPRs, one v_readfirstlane pair per VALU result
 	const bool bad = !(d > T(0)) || !(d < T(1e300));
 	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
-	d = bad ? T(1) : d;
+	if (!(VAR & 32)) d = bad ? T(1) : d;          // ... and is not replaced when it fails (compare -> lane mask -> select is a second trip through the SGPRs on the chain): NaN from there on
 	T rl = (VAR & 8) ? (T)__builtin_amdgcn_rsqf((float)d) : (T)__builtin_amdgcn_rsq(d);          // bit 3: fp32 estimate
 	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
 	if (!(VAR & 4)) rl = rl * (T(1.5) - T(0.5) * d * rl * rl);          // bit 2: ONE Newton step
@@ -255,7 +264,7 @@ int main()
 	double *din, *dL, *dW; long long* dc;
 	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 24));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 8; ++var) {
+	for (int var = 0; var < 11; ++var) {
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
@@ -263,7 +272,10 @@ int main()
 		else if (var == 4) hipLaunchKernelGGL(diag2_kernel, dim3(1), dim3(128), nblk * 256 * 8 + sizeof(Comm), 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 5) hipLaunchKernelGGL(diag_kernel<4>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 6) hipLaunchKernelGGL(diag_kernel<8>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag_kernel<12>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 7) hipLaunchKernelGGL(diag_kernel<12>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 8) hipLaunchKernelGGL(diag_kernel<16>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 9) hipLaunchKernelGGL(diag_kernel<32>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_kernel<33>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
