@@ -4,7 +4,10 @@
 // v_permlane16_swap / v_permlane32_swap row broadcasts, the next pivot taken from its own one-FMA update (no permute on the chain).
 // Variants 2 / 3: the same with the pivot made opaque to hipcc's uniformity analysis.  Variant 4: factor and inverse on TWO waves.
 // Prints cycles per block and the largest error against a host factorisation.  (Measured: 8467 / 9031 / 8788 / 9183 / 9100-9500 with the factor wave alone at 8500-8800; variants 5-7: one Newton step 8207, fp32 estimate 8413, both 8260; 8: lane masks recomputed per pivot instead of hoisted + spilled 10741;
-// 9 / 10: the pivot broadcast kept in vector registers and no select on a failing pivot 9564 / 10038.  The shipped form is the fastest of the eleven.)
+// 9 / 10: the pivot broadcast kept in vector registers and no select on a failing pivot 9564 / 10038.  11: lane conditions folded into the data (778 instead of 1300 vector instructions, 114 instead of 420 selects, nothing spilled): 8238-8442;
+// 12: 11 + no LDS round trip on the pivot chain: 8098.  An in-order wave stalls at the wait for the l_kj gathers of pivot J before it can
+// issue pivot J+1's chain, whatever is on the data path -- only a hand-pipelined order (next column updated through a scalar broadcast,
+// bulk update one pivot behind) would change that.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -88,6 +91,103 @@ __device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int
 		const T nw = w[c] - mi * ws;
 		w[c] = (i == J) ? ws : ((i > J) ? nw : w[c]);
 	}
+}
+
+// ---- "lean" pivot (variant 11): the same arithmetic with the lane conditions folded into the DATA instead of 26 selects per pivot.
+//   * multiplier column zeroed on the rows at or above the pivot (ONE select, mask i > J): rows that are finished get a zero multiplier,
+//     columns at or left of the pivot get a zero l_kj -- the (k > J && i >= k) guards of the update become unnecessary;
+//   * the strict upper triangle of `a` is allowed to fill with garbage: it is only ever read through that zeroed multiplier column
+//     and never stored;
+//   * the inverse: w <- w * f - mi0 * (w_J * rl) with f = rl on the pivot row and 1 elsewhere (ONE select).
+// Masks needed: (i > J), (i == J) per pivot and (q == qj): 36 SGPR pairs in all -- nothing spills.
+template <int J>
+__device__ __forceinline__ void pivot_lean(T (&a)[4], T (&w)[4], int q, int i, int& first_bad)
+{
+	constexpr int qj = J >> 2, cj = J & 3;
+	T d = bcast(a[cj], 16 * qj + J);
+	const bool bad = !(d > T(0)) || !(d < T(1e300));
+	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
+	d = bad ? T(1) : d;
+	T rl = (T)__builtin_amdgcn_rsq(d);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	const T colv = a[cj] * rl;                        // on the pivot lane: d * rl = l_jj
+	a[cj] = (q == qj) ? colv : a[cj];
+	const T colv0 = (i > J) ? colv : T(0);
+	const T mi0 = __shfl(colv0, 16 * qj + i, 64);
+	const T f = (i == J) ? rl : T(1);
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const T lk0 = __shfl(colv0, 16 * qj + 4 * q + c, 64);
+		const T wj = __shfl(w[c], 16 * q + J, 64);
+		a[c] = a[c] - mi0 * lk0;
+		w[c] = w[c] * f - mi0 * (wj * rl);
+	}
+}
+// variant 12: lean + no LDS round trip on the pivot chain: the multiplier column reaches the other rows through the two row-swap
+// instructions, the next pivot comes from its own FMA, the pivot row of the inverse through DPP; only the four l_kj gathers still use LDS
+template <int J>
+__device__ __forceinline__ void pivot_lean2(T (&a)[4], T (&w)[4], T& dnext, int q, int i, int& first_bad)
+{
+	constexpr int qj = J >> 2, cj = J & 3;
+	T d = (J > 0) ? bcast(dnext, 16 * qj + J) : bcast(a[cj], 16 * qj + J);
+	const bool bad = !(d > T(0)) || !(d < T(1e300));
+	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
+	d = bad ? T(1) : d;
+	T rl = (T)__builtin_amdgcn_rsq(d);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	const T colv = a[cj] * rl;
+	a[cj] = (q == qj) ? colv : a[cj];
+	const T colv0 = (i > J) ? colv : T(0);
+	const T mi0 = row_bcast<qj>(colv0);
+	if constexpr (J + 1 < 16) { constexpr int cn = (J + 1) & 3; dnext = a[cn] - mi0 * mi0; }
+	const T f = (i == J) ? rl : T(1);
+#pragma unroll
+	for (int c = 0; c < 4; ++c) {
+		const T lk0 = __shfl(mi0, 16 * q + 4 * q + c, 64);
+		const T wj = lane_bcast<J>(w[c]);
+		a[c] = a[c] - mi0 * lk0;
+		w[c] = w[c] * f - mi0 * (wj * rl);
+	}
+}
+template <int VARIANT, int J>
+__device__ __forceinline__ void lean_run(T (&a)[4], T (&w)[4], T& dnext, int q, int i, int& fb)
+{
+	if constexpr (VARIANT == 0) pivot_lean<J>(a, w, q, i, fb); else pivot_lean2<J>(a, w, dnext, q, i, fb);
+	if constexpr (J + 1 < 16) lean_run<VARIANT, J + 1>(a, w, dnext, q, i, fb);
+}
+template <int VARIANT>
+__global__ __launch_bounds__(64) void diag_lean_kernel(const T* __restrict__ in, T* __restrict__ outL, T* __restrict__ outW, int nblk, int reps, long long* cycles)
+{
+	extern __shared__ T S[];
+	const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+	for (int t = lane; t < nblk * 256; t += 64) S[t] = in[t];
+	__syncthreads();
+	long long t0 = 0;
+	for (int r = 0; r <= reps; ++r) {
+		if (r == 1) t0 = __builtin_amdgcn_s_memtime();
+		for (int b = 0; b < nblk; ++b) {
+			T a[4], w[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				a[c] = (col <= i) ? S[b * 256 + i * 16 + col] : T(0);
+				w[c] = (col == i) ? T(1) : T(0);
+			}
+			int first_bad = 0;
+			T dnext = 0;
+			lean_run<VARIANT, 0>(a, w, dnext, q, i, first_bad);
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				outL[b * 256 + i * 16 + col] = (col <= i) ? a[c] : T(0);
+				outW[b * 256 + i * 16 + col] = (col <= i) ? w[c] : T(0);
+			}
+			if (first_bad) outL[0] = -1;
+		}
+	}
+	if (lane == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
 template <int VAR>
@@ -264,7 +364,7 @@ int main()
 	double *din, *dL, *dW; long long* dc;
 	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 24));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 11; ++var) {
+	for (int var = 0; var < 13; ++var) {
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
@@ -275,7 +375,9 @@ int main()
 		else if (var == 7) hipLaunchKernelGGL(diag_kernel<12>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 8) hipLaunchKernelGGL(diag_kernel<16>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 9) hipLaunchKernelGGL(diag_kernel<32>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag_kernel<33>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 10) hipLaunchKernelGGL(diag_kernel<33>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 11) hipLaunchKernelGGL(diag_lean_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_lean_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
