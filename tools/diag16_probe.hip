@@ -7,7 +7,8 @@
 // 9 / 10: the pivot broadcast kept in vector registers and no select on a failing pivot 9564 / 10038.  11: lane conditions folded into the data (778 instead of 1300 vector instructions, 114 instead of 420 selects, nothing spilled): 8238-8442;
 // 12: 11 + no LDS round trip on the pivot chain: 8098.  An in-order wave stalls at the wait for the l_kj gathers of pivot J before it can
 // issue pivot J+1's chain, whatever is on the data path -- only a hand-pipelined order (next column updated through a scalar broadcast,
-// bulk update one pivot behind) would change that.)
+// bulk update one pivot behind) would change that -- variant 13 is exactly that order, correct, and 8263: it does not.  All thirteen forms
+// land within 8000-10700; whatever bounds the pivot step is common to all of them and was not found with black-box variants.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -151,6 +152,96 @@ __device__ __forceinline__ void pivot_lean2(T (&a)[4], T (&w)[4], T& dnext, int 
 		w[c] = w[c] * f - mi0 * (wj * rl);
 	}
 }
+// ---- variant 13: the lean pivot, HAND-PIPELINED: the bulk update of pivot J - 1 (which waits for its four l_kj gathers) is issued
+// AFTER pivot J's chain, and pivot J + 1's column is prepared from a scalar broadcast of l_{J+1,J}; the in-order wave never waits for an
+// LDS gather issued in the same iteration.
+struct PipeState { T mi0, rl, f, colS, lk0[4]; };
+template <int J>
+__device__ __forceinline__ void pivot_pipe(T (&a)[4], T (&w)[4], T& colJ, PipeState& prev, int q, int i, int& first_bad)
+{
+	constexpr int qj = J >> 2, cj = J & 3;
+	// 1. chain of pivot J on its prepared column
+	T d = bcast(colJ, 16 * qj + J);
+	const bool bad = !(d > T(0)) || !(d < T(1e300));
+	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
+	d = bad ? T(1) : d;
+	T rl = (T)__builtin_amdgcn_rsq(d);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+	const T colv = colJ * rl;
+	const T colv0 = (i > J) ? colv : T(0);
+	const T mi0 = row_bcast<qj>(colv0);
+	PipeState cur;
+	cur.mi0 = mi0; cur.rl = rl; cur.f = (i == J) ? rl : T(1); cur.colS = colv;
+	// 2. gathers of pivot J (consumed one iteration later)
+#pragma unroll
+	for (int c = 0; c < 4; ++c) cur.lk0[c] = __shfl(mi0, 16 * q + 4 * q + c, 64);
+	// 3. bulk update of pivot J - 1, then the scaled column J - 1 goes into its place
+	if constexpr (J > 0) {
+		constexpr int qp = (J - 1) >> 2, cp = (J - 1) & 3;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			const T wj = lane_bcast<J - 1>(w[c]);
+			a[c] = a[c] - prev.mi0 * prev.lk0[c];
+			w[c] = w[c] * prev.f - prev.mi0 * (wj * prev.rl);
+		}
+		a[cp] = (q == qp) ? prev.colS : a[cp];
+	}
+	// 4. column J + 1, brought up to date with pivot J through a scalar broadcast of l_{J+1,J}
+	if constexpr (J + 1 < 16) {
+		constexpr int cn = (J + 1) & 3;
+		const T s = bcast(colv0, 16 * qj + J + 1);
+		colJ = a[cn] - mi0 * s;
+	}
+	prev = cur;
+}
+template <int J>
+__device__ __forceinline__ void pipe_run(T (&a)[4], T (&w)[4], T& colJ, PipeState& prev, int q, int i, int& fb)
+{
+	pivot_pipe<J>(a, w, colJ, prev, q, i, fb);
+	if constexpr (J + 1 < 16) pipe_run<J + 1>(a, w, colJ, prev, q, i, fb);
+}
+__global__ __launch_bounds__(64) void diag_pipe_kernel(const T* __restrict__ in, T* __restrict__ outL, T* __restrict__ outW, int nblk, int reps, long long* cycles)
+{
+	extern __shared__ T S[];
+	const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+	for (int t = lane; t < nblk * 256; t += 64) S[t] = in[t];
+	__syncthreads();
+	long long t0 = 0;
+	for (int r = 0; r <= reps; ++r) {
+		if (r == 1) t0 = __builtin_amdgcn_s_memtime();
+		for (int b = 0; b < nblk; ++b) {
+			T a[4], w[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				a[c] = (col <= i) ? S[b * 256 + i * 16 + col] : T(0);
+				w[c] = (col == i) ? T(1) : T(0);
+			}
+			int first_bad = 0;
+			T colJ = a[0];
+			PipeState prev;
+			pipe_run<0>(a, w, colJ, prev, q, i, first_bad);
+			// drain: bulk update of pivot 15 (only its scaling of row 15 of the inverse and the scaled column matter)
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const T wj = lane_bcast<15>(w[c]);
+				a[c] = a[c] - prev.mi0 * prev.lk0[c];
+				w[c] = w[c] * prev.f - prev.mi0 * (wj * prev.rl);
+			}
+			a[3] = (q == 3) ? prev.colS : a[3];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				outL[b * 256 + i * 16 + col] = (col <= i) ? a[c] : T(0);
+				outW[b * 256 + i * 16 + col] = (col <= i) ? w[c] : T(0);
+			}
+			if (first_bad) outL[0] = -1;
+		}
+	}
+	if (lane == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
+}
+
 template <int VARIANT, int J>
 __device__ __forceinline__ void lean_run(T (&a)[4], T (&w)[4], T& dnext, int q, int i, int& fb)
 {
@@ -364,7 +455,7 @@ int main()
 	double *din, *dL, *dW; long long* dc;
 	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 24));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 13; ++var) {
+	for (int var = 0; var < 14; ++var) {
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
@@ -377,7 +468,8 @@ int main()
 		else if (var == 9) hipLaunchKernelGGL(diag_kernel<32>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 10) hipLaunchKernelGGL(diag_kernel<33>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 11) hipLaunchKernelGGL(diag_lean_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag_lean_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 12) hipLaunchKernelGGL(diag_lean_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_pipe_kernel, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
