@@ -8,7 +8,9 @@
 // 12: 11 + no LDS round trip on the pivot chain: 8098.  An in-order wave stalls at the wait for the l_kj gathers of pivot J before it can
 // issue pivot J+1's chain, whatever is on the data path -- only a hand-pipelined order (next column updated through a scalar broadcast,
 // bulk update one pivot behind) would change that -- variant 13 is exactly that order, correct, and 8263: it does not.  All thirteen forms
-// land within 8000-10700; whatever bounds the pivot step is common to all of them and was not found with black-box variants.)
+// land within 8000-10700.  Ablations (wrong numbers, timing only): no pivots at all 384; no rsqrt / Newton 7988; only the next pivot's column
+// updated and no inverse 4136; both 3461; the shipped form with only the inverse's pivot row through DPP 7964.  So about half of a pivot is
+// its chain (one LDS round trip) and half the bulk update, and neither the number of vector instructions nor of permutes in the bulk moves it.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -64,8 +66,11 @@ __device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int
 	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
 	if (!(VAR & 32)) d = bad ? T(1) : d;          // ... and is not replaced when it fails (compare -> lane mask -> select is a second trip through the SGPRs on the chain): NaN from there on
 	T rl = (VAR & 8) ? (T)__builtin_amdgcn_rsqf((float)d) : (T)__builtin_amdgcn_rsq(d);          // bit 3: fp32 estimate
+	if (VAR & 128) rl = d * T(0.5);          // bit 7 (timing ablation, wrong numbers): no reciprocal square root, no Newton steps
+	else {
 	rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
 	if (!(VAR & 4)) rl = rl * (T(1.5) - T(0.5) * d * rl * rl);          // bit 2: ONE Newton step
+	}
 	const T l = d * rl;
 	const T colv = (i == J) ? l : a[cj] * rl;
 	a[cj] = (q == qj && i >= J) ? colv : a[cj];
@@ -73,7 +78,7 @@ __device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int
 	if (!(VAR & 1)) {
 		mi = __shfl(colv, 16 * qj + i, 64);
 #pragma unroll
-		for (int c = 0; c < 4; ++c) { lk[c] = __shfl(colv, 16 * qj + 4 * q + c, 64); wj[c] = __shfl(w[c], 16 * q + J, 64); }
+		for (int c = 0; c < 4; ++c) { lk[c] = __shfl(colv, 16 * qj + 4 * q + c, 64); wj[c] = (VAR & 512) ? lane_bcast<J>(w[c]) : __shfl(w[c], 16 * q + J, 64); }          // bit 9: ONLY the pivot row of the inverse through DPP
 	} else {
 		mi = row_bcast<qj>(colv);
 		if (J + 1 < 16) {          // the next pivot's diagonal element, by the same FMA the update below applies to it (l_kj = l_ij on the diagonal)
@@ -87,10 +92,10 @@ __device__ __forceinline__ void pivot(T (&a)[4], T (&w)[4], T& dnext, int q, int
 	for (int c = 0; c < 4; ++c) {
 		const int k = 4 * q + c;
 		const T na = a[c] - mi * lk[c];
-		a[c] = (k > J && i >= k) ? na : a[c];
+		if (!(VAR & 256) || c == ((J + 1) & 3)) a[c] = (k > J && i >= k) ? na : a[c];          // bit 8 (timing ablation): only the next pivot's column is updated
 		const T ws = wj[c] * rl;
 		const T nw = w[c] - mi * ws;
-		w[c] = (i == J) ? ws : ((i > J) ? nw : w[c]);
+		if (!(VAR & 256)) w[c] = (i == J) ? ws : ((i > J) ? nw : w[c]);
 	}
 }
 
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(64) void diag_kernel(const T* __restrict__ in, T* _
 				w[c] = (col == i) ? T(1) : T(0);
 			}
 			int first_bad = 0;
+			if constexpr (VAR != 64) {          // (64: no pivots at all -- the cost of the block loop around them)
 			pivot<VAR, 0>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 1>(a, w, dnext, q, i, lane, first_bad);
 			pivot<VAR, 2>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 3>(a, w, dnext, q, i, lane, first_bad);
 			pivot<VAR, 4>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 5>(a, w, dnext, q, i, lane, first_bad);
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(64) void diag_kernel(const T* __restrict__ in, T* _
 			pivot<VAR, 10>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 11>(a, w, dnext, q, i, lane, first_bad);
 			pivot<VAR, 12>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 13>(a, w, dnext, q, i, lane, first_bad);
 			pivot<VAR, 14>(a, w, dnext, q, i, lane, first_bad); pivot<VAR, 15>(a, w, dnext, q, i, lane, first_bad);
+			}
 #pragma unroll
 			for (int c = 0; c < 4; ++c) {
 				const int col = 4 * q + c;
@@ -455,7 +462,7 @@ int main()
 	double *din, *dL, *dW; long long* dc;
 	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 24));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 14; ++var) {
+	for (int var = 0; var < 19; ++var) {
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
@@ -469,7 +476,12 @@ int main()
 		else if (var == 10) hipLaunchKernelGGL(diag_kernel<33>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 11) hipLaunchKernelGGL(diag_lean_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 12) hipLaunchKernelGGL(diag_lean_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag_pipe_kernel, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 13) hipLaunchKernelGGL(diag_pipe_kernel, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 14) hipLaunchKernelGGL(diag_kernel<64>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 15) hipLaunchKernelGGL(diag_kernel<128>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 16) hipLaunchKernelGGL(diag_kernel<256>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 17) hipLaunchKernelGGL(diag_kernel<384>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_kernel<512>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
