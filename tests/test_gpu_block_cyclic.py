@@ -162,3 +162,24 @@ def test_bench_self_launch_two_ranks_gloo():
 	assert mg["backend"] == "gloo" and mg["grid"] == "1x2" and len(mg["per_rank"]) == 2
 	assert mg["selfcheck"]["mu_rel_err_vs_single_gpu_class"] < 1e-8 and mg["selfcheck"]["sigma_rel_err"] < 1e-8
 	assert not out["result_check"]["nan"]
+
+
+def test_bench_more_ranks_than_gpus_prints_one_json_error_line():
+	"""`python bench.py --gpus 2` on the RCCL backend with ONE visible GPU: the ranks cannot get a device each; the run must end within
+	seconds with exactly one JSON line carrying `value: null` and the reason, and a non-zero exit code (no hang, no bare traceback)."""
+	import json
+	import subprocess
+	import sys
+	import torch
+	if torch.cuda.device_count() >= 2:
+		pytest.skip("this box has a GPU per rank")
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	env = dict(os.environ)
+	for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "STPY_BENCH_BACKEND"):
+		env.pop(k, None)
+	r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "4096", "--no-cpu-baseline", "--no-extra-configs"],
+					   capture_output=True, text=True, timeout=300, env=env, cwd=root)
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+	assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+	out = json.loads(lines[0])
+	assert out["value"] is None and out["n_gpus"] == 2 and "GPUs" in out["error"]
