@@ -10,7 +10,13 @@
 // bulk update one pivot behind) would change that -- variant 13 is exactly that order, correct, and 8263: it does not.  All thirteen forms
 // land within 8000-10700.  Ablations (wrong numbers, timing only): no pivots at all 384; no rsqrt / Newton 7988; only the next pivot's column
 // updated and no inverse 4136; both 3461; the shipped form with only the inverse's pivot row through DPP 7964.  So about half of a pivot is
-// its chain (one LDS round trip) and half the bulk update, and neither the number of vector instructions nor of permutes in the bulk moves it.)
+// its chain (one LDS round trip) and half the bulk update.
+// Counters of single variants (`diag16_probe <variant>` under rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+// SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU), per block: the one wave executes strictly one instruction at a
+// time -- 4.3 cycles per vector instruction, 8 per LDS permute -- plus the waits:   variant 0: 983 VALU = 4126 cycles, 279 LDS = 2216,
+// SALU 375, wait 1700 (sum 8484);   11 (lean): 604 / 2610, 279 / 2216, wait 3166 (fewer independent instructions to fill the permute latency);
+// 12: 1003 / 4454, 128 / 1008, wait 2054;   18: 1234 / 5126, 154 / 1216, wait 1196;   19 (order pinned by hand: the bulk update of pivot
+// J - 1 dealt out between the dependent instructions of pivot J's chain): 1079 / 4758, 128 / 1008, wait 1537 = 7777, the best form, -8 %.)
 // build: hipcc --offload-arch=gfx950 -O3 -o diag16_probe tools/diag16_probe.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -247,6 +253,121 @@ __global__ __launch_bounds__(64) void diag_pipe_kernel(const T* __restrict__ in,
 	if (lane == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
 }
 
+// ---- variant 19: variant 13 with the ORDER pinned by hand (sched_barrier): the bulk update of pivot J - 1 (26 independent vector
+// instructions) is dealt out between the mutually dependent instructions of pivot J's chain (broadcast, rsqrt, two Newton steps, scale,
+// row swaps), so that the one wave issues something every slot instead of stalling on each result; the inverse's pivot row through DPP.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+template <int J>
+__device__ __forceinline__ void pivot_pipe2(T (&a)[4], T (&w)[4], T& colJ, PipeState& prev, int q, int i, int& first_bad)
+{
+	constexpr int qj = J >> 2, cj = J & 3;
+	constexpr bool HAVE = J > 0;
+	constexpr int JP = HAVE ? J - 1 : 0, qp = JP >> 2, cp = JP & 3;
+	T wj[4], t[4];
+	// chain: the pivot ...
+	T d = bcast(colJ, 16 * qj + J);
+	if (HAVE) { a[0] = a[0] - prev.mi0 * prev.lk0[0]; a[1] = a[1] - prev.mi0 * prev.lk0[1]; }
+	SB();
+	const bool bad = !(d > T(0)) || !(d < T(1e300));
+	first_bad = (bad && first_bad == 0) ? J + 1 : first_bad;
+	d = bad ? T(1) : d;
+	if (HAVE) { a[2] = a[2] - prev.mi0 * prev.lk0[2]; a[3] = a[3] - prev.mi0 * prev.lk0[3]; }
+	SB();
+	T rl = (T)__builtin_amdgcn_rsq(d);
+	if (HAVE) { wj[0] = lane_bcast<JP>(w[0]); wj[1] = lane_bcast<JP>(w[1]); }
+	SB();
+	T u = d * rl;
+	if (HAVE) { wj[2] = lane_bcast<JP>(w[2]); }
+	SB();
+	u = u * rl;
+	if (HAVE) { wj[3] = lane_bcast<JP>(w[3]); }
+	SB();
+	u = T(1.5) - T(0.5) * u;
+	if (HAVE) { t[0] = wj[0] * prev.rl; }
+	SB();
+	rl = rl * u;
+	if (HAVE) { t[1] = wj[1] * prev.rl; }
+	SB();
+	u = d * rl;
+	if (HAVE) { t[2] = wj[2] * prev.rl; }
+	SB();
+	u = u * rl;
+	if (HAVE) { t[3] = wj[3] * prev.rl; }
+	SB();
+	u = T(1.5) - T(0.5) * u;
+	if (HAVE) { w[0] = w[0] * prev.f; }
+	SB();
+	rl = rl * u;
+	if (HAVE) { w[1] = w[1] * prev.f; }
+	SB();
+	const T colv = colJ * rl;
+	if (HAVE) { w[2] = w[2] * prev.f; }
+	SB();
+	const T colv0 = (i > J) ? colv : T(0);
+	if (HAVE) { w[3] = w[3] * prev.f; }
+	SB();
+	const T mi0 = row_bcast<qj>(colv0);
+	if (HAVE) { w[0] = w[0] - prev.mi0 * t[0]; w[1] = w[1] - prev.mi0 * t[1]; }
+	SB();
+	PipeState cur;
+	cur.mi0 = mi0; cur.rl = rl; cur.f = (i == J) ? rl : T(1); cur.colS = colv;
+#pragma unroll
+	for (int c = 0; c < 4; ++c) cur.lk0[c] = __shfl(mi0, 16 * q + 4 * q + c, 64);
+	if (HAVE) { w[2] = w[2] - prev.mi0 * t[2]; w[3] = w[3] - prev.mi0 * t[3]; a[cp] = (q == qp) ? prev.colS : a[cp]; }
+	SB();
+	if constexpr (J + 1 < 16) {
+		constexpr int cn = (J + 1) & 3;
+		const T sN = bcast(colv0, 16 * qj + J + 1);
+		colJ = a[cn] - mi0 * sN;
+	}
+	prev = cur;
+}
+template <int J>
+__device__ __forceinline__ void pipe2_run(T (&a)[4], T (&w)[4], T& colJ, PipeState& prev, int q, int i, int& fb)
+{
+	pivot_pipe2<J>(a, w, colJ, prev, q, i, fb);
+	if constexpr (J + 1 < 16) pipe2_run<J + 1>(a, w, colJ, prev, q, i, fb);
+}
+__global__ __launch_bounds__(64) void diag_pipe2_kernel(const T* __restrict__ in, T* __restrict__ outL, T* __restrict__ outW, int nblk, int reps, long long* cycles)
+{
+	extern __shared__ T S[];
+	const int lane = threadIdx.x, q = lane >> 4, i = lane & 15;
+	for (int t = lane; t < nblk * 256; t += 64) S[t] = in[t];
+	__syncthreads();
+	long long t0 = 0;
+	for (int r = 0; r <= reps; ++r) {
+		if (r == 1) t0 = __builtin_amdgcn_s_memtime();
+		for (int b = 0; b < nblk; ++b) {
+			T a[4], w[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				a[c] = (col <= i) ? S[b * 256 + i * 16 + col] : T(0);
+				w[c] = (col == i) ? T(1) : T(0);
+			}
+			int first_bad = 0;
+			T colJ = a[0];
+			PipeState prev;
+			pipe2_run<0>(a, w, colJ, prev, q, i, first_bad);
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const T wjl = lane_bcast<15>(w[c]);
+				a[c] = a[c] - prev.mi0 * prev.lk0[c];
+				w[c] = w[c] * prev.f - prev.mi0 * (wjl * prev.rl);
+			}
+			a[3] = (q == 3) ? prev.colS : a[3];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				outL[b * 256 + i * 16 + col] = (col <= i) ? a[c] : T(0);
+				outW[b * 256 + i * 16 + col] = (col <= i) ? w[c] : T(0);
+			}
+			if (first_bad) outL[0] = -1;
+		}
+	}
+	if (lane == 0) *cycles = (long long)__builtin_amdgcn_s_memtime() - t0;
+}
+
 template <int VARIANT, int J>
 __device__ __forceinline__ void lean_run(T (&a)[4], T (&w)[4], T& dnext, int q, int i, int& fb)
 {
@@ -431,8 +552,9 @@ __global__ void perm_check(unsigned* o)
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-int main()
+int main(int argc, char** argv)
 {
+	const int only = argc > 1 ? atoi(argv[1]) : -1;          // one variant only (target for rocprofv3 --pmc passes)
 	unsigned* po; CK(hipMalloc(&po, 320 * 4));
 	hipLaunchKernelGGL(perm_check, dim3(1), dim3(64), 0, 0, po);
 	std::vector<unsigned> ph(320); CK(hipMemcpy(ph.data(), po, 320 * 4, hipMemcpyDeviceToHost));
@@ -462,7 +584,8 @@ int main()
 	double *din, *dL, *dW; long long* dc;
 	CK(hipMalloc(&din, A.size() * 8)); CK(hipMalloc(&dL, A.size() * 8)); CK(hipMalloc(&dW, A.size() * 8)); CK(hipMalloc(&dc, 24));
 	CK(hipMemcpy(din, A.data(), A.size() * 8, hipMemcpyHostToDevice));
-	for (int var = 0; var < 19; ++var) {
+	for (int var = 0; var < 20; ++var) {
+		if (only >= 0 && var != only) continue;
 		if (var == 0) hipLaunchKernelGGL(diag_kernel<0>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 1) hipLaunchKernelGGL(diag_kernel<1>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 2) hipLaunchKernelGGL(diag_kernel<2>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
@@ -481,7 +604,8 @@ int main()
 		else if (var == 15) hipLaunchKernelGGL(diag_kernel<128>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 16) hipLaunchKernelGGL(diag_kernel<256>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		else if (var == 17) hipLaunchKernelGGL(diag_kernel<384>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
-		else hipLaunchKernelGGL(diag_kernel<512>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else if (var == 18) hipLaunchKernelGGL(diag_kernel<512>, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
+		else hipLaunchKernelGGL(diag_pipe2_kernel, dim3(1), dim3(64), nblk * 256 * 8, 0, din, dL, dW, nblk, reps, dc);
 		CK(hipDeviceSynchronize());
 		std::vector<double> Lg(A.size()), Wg(A.size()); long long cyc = 0;
 		CK(hipMemcpy(Lg.data(), dL, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Wg.data(), dW, A.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost));
