@@ -111,6 +111,10 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,
  *       inverse(L_cc) of every 128x128 diagonal block (reused by the triangular solves below).
  * work: stpy_potrf_workspace_bytes(dtype, n, nb) bytes.   nb: outer panel width, multiple of 128
  *       (0 = library default).   info_dev: device int32.
+ *       The workspace holds two panel buffers of n x (widest panel) elements.  With nb = 0 the widest panel follows the size:
+ *       256 / 512 / 1024 columns up to 2048 / 16 384 / 32 768 rows and 2048 above (since library 0.3: the K = 2048 trailing updates),
+ *       i.e. 0.54 GB at n = 32 768, 2.1 GB at n = 65 536 and 4.3 GB at n = 131 072 in fp64 -- on top of the in-place matrix.  ALWAYS
+ *       size it by the query for the same (dtype, n, nb): a buffer sized by an older build's formula is refused with -20, not overrun.
  */
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb);
 int64_t stpy_potrf_winv_elems(int64_t n);
@@ -167,7 +171,8 @@ int stpy_predict_finish(int dtype, int64_t m, void* mu, const void* sumsq, const
                         void* sigma, int clamp, void* stream);
 
 /* out (op)= src elementwise on an m x n window, then + diag_add on the diagonal: the + / * algebra of kernels.py:146-157
- * for an item that was first summed into scratch (combine: STPY_OUT_SET / _ADD / _MUL). */
+ * for an item that was first summed into scratch (combine: STPY_OUT_SET / _ADD / _MUL).  src == out is allowed (with STPY_OUT_SET:
+ * "add diag_add to the diagonal in place"). */
 int stpy_combine(int dtype, int64_t m, int64_t n, void* out, int64_t ldo, const void* src, int64_t lds,
                  int combine, double diag_add, void* stream);
 
@@ -177,7 +182,7 @@ int stpy_logdet_quad(int dtype, int64_t n, const void* L, int64_t ldl, const voi
 
 /* C (op) A B^T with A: m x k, B: n x k, C: m x n.  mode 0: C = A B^T, 1: C -= A B^T, 2: C += A B^T (slab-wise accumulation
  * of Phi^T Phi in the feature-space normal equations, kernelized_features.py:236-240).
- * lower_only: skip 128x128 tiles strictly above the diagonal (m == n).  This is the MFMA
+ * lower_only: skip 128x128 tiles strictly above the diagonal (m == n).  ldc must be below 2^25 elements (-10).  This is the MFMA
  * contraction under potrf / trsm; exported for the roofline bench and the full-covariance
  * branch gauss_procc.py:396-399. */
 int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k,
@@ -211,6 +216,27 @@ int stpy_gemm_nt_bc(int dtype, int64_t m, int64_t n, int64_t k,
 
 /* mirror the lower triangle into the upper one (n x n) -- materialises .K after a lower-only Gram */
 int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stream);
+
+/* zero the strict upper triangle of A (n x n): the in-place factor of stpy_potrf as a proper lower-triangular operand of
+ * stpy_gemm_nt -- L r of the samplers (gauss_procc.py:472-474, kernelized_features.py:328-330) */
+int stpy_tril(int dtype, int64_t n, void* A, int64_t lda, void* stream);
+
+/* out2[0] = tr(A) (A: n x n; NULL: 0),  out2[1] = <u, v> (n elements each; u NULL: 0) in a fixed summation order -- the scalar
+ * tr(w K^-1) - alpha^T alpha of the noise gradient of the evidence (dK/ds = 2 s I), alpha^T y of GaussianProcess.norm
+ * (gauss_procc.py:179-184), tr(V^-1) of KernelizedFeatures.effective_dim (kernelized_features.py:103-106) */
+int stpy_trace_dot(int dtype, int64_t n, const void* A, int64_t lda, const void* u, const void* v, void* out2, void* stream);
+
+/* out[k*ldo + i] = x[i*ldx + cols[k]] * inv_ls[k] for k < d (cols NULL: k), and out[d*ldo + i] = 1 when ones_row != 0:
+ * [Xs | 1]^T, the "row x K" operand of the evidence gradient's H [Xs | 1] product (see stpy_lml_weight). out: (d + ones_row) x n. */
+int stpy_scaled_points_t(int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
+                         void* out, int64_t ldo, int ones_row, void* stream);
+
+/* The last step of the evidence gradient w.r.t. the lengthscales of one kernel term: with P = H [Xs | 1] (n x (d+1), ldp >= d+1),
+ *   acc[pidx[k]] += inv_ls[k] * sum_i ( xs_ik^2 P_id - xs_ik P_ik ),   xs_ik = x[i*ldx + cols[k]] * inv_ls[k],   k < d
+ * ( = inv_ls[k]/2 * sum_ij H_ij (xs_ik - xs_jk)^2 ).  pidx: device int32[d], the parameter slot of coordinate k (all zero for an
+ * isotropic 'gamma'; NULL: k); acc is accumulated in coordinate order by one workgroup, so the result is reproducible. */
+int stpy_lml_grad_reduce(int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
+                         const void* P, int64_t ldp, const int32_t* pidx, void* acc, void* stream);
 
 /*
  * Random Fourier features, replaces RFFEmbedding.embed (embedding.py:225-241):

@@ -460,6 +460,85 @@ def kernelized_features_mean_std(Qtest, invV, theta, s):
 	return mean, np.sqrt(diag)
 
 
+def kernelized_features_dual_fit(Q, y, s, lam):
+	"""kernelized_features.py:229-235 + :252-254 (dual, n < m with primal=False): K = Q Q^T + s^2 lam I, invK = pinv(K),
+	invK_V = (I - Q^T invK Q) / lam, theta = Q^T invK y."""
+	Q = np.asarray(Q, dtype=np.float64)
+	n, m = Q.shape
+	K = Q @ Q.T + s ** 2 * lam * np.eye(n)
+	invK = np.linalg.pinv(K)
+	invK_V = (1. / lam) * (-Q.T @ invK @ Q + np.eye(m))
+	theta = Q.T @ invK @ np.asarray(y, dtype=np.float64).reshape(-1, 1)
+	return K, invK_V, theta
+
+
+def kernelized_features_dual_mean_std(Qtest, invK_V, theta):
+	"""kernelized_features.py:279, :285-287 (dual): mean = Phi* theta, std = sqrt(diag(Phi* invK_V Phi*^T))."""
+	Qtest = np.asarray(Qtest, dtype=np.float64)
+	return Qtest @ theta, np.sqrt(np.einsum('ij,jk,ik->i', Qtest, invK_V, Qtest).reshape(-1, 1))
+
+
+def kernelized_features_dual_get_invV(Q, s, lam):
+	"""kernelized_features.py:167-172 (get_invV in the dual form): V = linear_kernel(Q^T, Q^T) + s^2 lam I with the linear kernel
+	object of :51 (default d = 1, so group = [0]: only the first COLUMN of Q^T, i.e. the features of the first data point,
+	enters) -- V = q0 q0^T + s^2 lam I."""
+	Q = np.asarray(Q, dtype=np.float64)
+	q0 = Q[0:1, :].T                                      # (m, 1)
+	V = q0 @ q0.T + s ** 2 * lam * np.eye(Q.shape[1])
+	return np.linalg.solve(V, np.eye(Q.shape[1]))
+
+
+def kernelized_features_sample_theta(theta_mean, invV, s, random_vector):
+	"""kernelized_features.py:327-330: L = chol(invV) s, theta = theta_mean + L r  (r: (basis, size) standard normals)."""
+	L = np.linalg.cholesky(np.asarray(invV, dtype=np.float64)) * s
+	return np.asarray(theta_mean, dtype=np.float64).reshape(-1, 1) + L @ np.asarray(random_vector, dtype=np.float64)
+
+
+def kernelized_features_prior_theta(lam, random_vector, prior_mean=0.0):
+	"""kernelized_features.py:305-307, :332-334: chol(lam I) r + prior_mean."""
+	return math.sqrt(lam) * np.asarray(random_vector, dtype=np.float64) + prior_mean
+
+
+def kernelized_features_sample_matheron(Q, Qtest, y, K_star, K_train, s, lam, random_vector, prior_mean=0.0):
+	"""kernelized_features.py:300-317: theta ~ prior; f = Phi* theta + K* pinv(K + s^2 lam I)(y - Phi theta).
+	K_star = kernel(x, xtest) (M, N), K_train = kernel(x, x) of the exact kernel object."""
+	theta = kernelized_features_prior_theta(lam, random_vector, prior_mean)
+	f_prior_xtest = np.asarray(Qtest, dtype=np.float64) @ theta
+	f_prior_x = np.asarray(Q, dtype=np.float64) @ theta
+	N = K_train.shape[0]
+	K = np.asarray(K_train, dtype=np.float64) + s ** 2 * lam * np.eye(N)
+	return f_prior_xtest + np.asarray(K_star, dtype=np.float64) @ np.linalg.pinv(K) @ (np.asarray(y, dtype=np.float64).reshape(-1, 1) - f_prior_x)
+
+
+def kernelized_features_first_feature_kernel(Qx, Qy, diag_add=0.0):
+	"""kernelized_features.py:93-97 / :553-557 with the linear kernel object of :51 (group = [0]): (|y|, |x|) outer product of the
+	FIRST feature column, + diag_add I."""
+	K = np.asarray(Qy, dtype=np.float64)[:, :1] @ np.asarray(Qx, dtype=np.float64)[:, :1].T
+	if diag_add:
+		K = K + diag_add * np.eye(K.shape[0])
+	return K
+
+
+def kernelized_features_logdet_ratio(K, s, lam, m):
+	"""kernelized_features.py:99-101: logdet(K) - logdet(s^2 lam I_m); K is the ones(1, 1) placeholder in the primal form."""
+	return np.linalg.slogdet(np.asarray(K, dtype=np.float64))[1] - m * math.log(s ** 2 * lam)
+
+
+def kernelized_features_effective_dim(Qtest, lam):
+	"""kernelized_features.py:103-106: trace of the solution X of (Phi^T Phi + lam I) X = Phi^T Phi."""
+	Q = np.asarray(Qtest, dtype=np.float64)
+	A = Q.T @ Q
+	return float(np.trace(np.linalg.solve(A + lam * np.eye(A.shape[0]), A)))
+
+
+def kernelized_features_beta_theory(Q, s, lam, bound, delta):
+	"""kernelized_features.py:64-73: bound lam + logdet(Q^T Q / s^2 + lam I) - logdet(lam I) + 2 log(1 / delta)."""
+	Q = np.asarray(Q, dtype=np.float64)
+	m = Q.shape[1]
+	V = Q.T @ Q / s ** 2 + lam * np.eye(m)
+	return bound * lam + np.linalg.slogdet(V)[1] - m * math.log(lam) + 2 * math.log(1. / delta)
+
+
 # --------------------------------------------------------------------------------------------
 # synthetic workloads shared by tests and bench  (SURVEY.md section 8d)
 # --------------------------------------------------------------------------------------------

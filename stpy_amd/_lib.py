@@ -49,6 +49,10 @@ SIGNATURES = {
 	"stpy_gemm_nt_splitk": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
 	"stpy_gemm_nt_bc": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 	"stpy_symmetrize_lower": (_i32, [_i32, _i64, _vp, _i64, _vp]),
+	"stpy_tril": (_i32, [_i32, _i64, _vp, _i64, _vp]),
+	"stpy_trace_dot": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+	"stpy_scaled_points_t": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+	"stpy_lml_grad_reduce": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
 	"stpy_rff_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
 	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _dbl, _vp, _i64, _i32, _vp, _i64, _vp]),
 	"stpy_profile_enable": (None, [_i32]),
@@ -90,6 +94,15 @@ def check(rc, what):
 		raise StpyHipError("%s failed (rc=%d): %s" % (what, rc, msg))
 
 
+def check_async(what, stream=None):
+	"""Read (and clear) the sticky device error word of the calling stream -- waits for the stream.  Raises StpyHipError when a
+	hand-off wait of the one-launch vector solve gave up (its output is NaN from the affected block on)."""
+	rc = load().stpy_async_status(stream_ptr() if stream is None else stream)
+	if rc != 0:
+		raise StpyHipError("%s: device-side failure reported by stpy_async_status (code %d%s)" % (
+			what, rc, ": a hand-off wait of the one-launch vector solve timed out, its result is NaN" if rc == 1 else ""))
+
+
 def device():
 	"""The ROCm device this process computes on (one process per GPU: LOCAL_RANK picks it)."""
 	if not torch.cuda.is_available():
@@ -111,6 +124,12 @@ def dtype_code(dt):
 
 def ptr(t):
 	return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def ld(t):
+	"""Leading dimension (elements) of a row-major 2-D tensor.  A one-row tensor reports whatever stride(0) its history left behind
+	(``x.T.contiguous()`` of an (n, 1) tensor keeps stride 1): there the row length is the only valid answer."""
+	return t.stride(0) if t.shape[0] > 1 else max(int(t.shape[1]), 1)
 
 
 def to_device(t, dtype=None):

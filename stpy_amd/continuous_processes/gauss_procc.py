@@ -160,8 +160,8 @@ class GaussianProcess(Estimator):
 		St = _lib.to_device(Sigma, K.dtype).t().contiguous()
 		nSt = -St
 		n = K.shape[0]
-		_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(K.dtype), n, n, St.shape[1], _lib.ptr(nSt), nSt.stride(0), _lib.ptr(St), St.stride(0),
-									_lib.ptr(K), K.stride(0), 1, 0, _lib.stream_ptr()), "stpy_gemm_nt")
+		_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(K.dtype), n, n, St.shape[1], _lib.ptr(nSt), _lib.ld(nSt), _lib.ptr(St), _lib.ld(St),
+									_lib.ptr(K), _lib.ld(K), 1, 0, _lib.stream_ptr()), "stpy_gemm_nt")
 
 	@staticmethod
 	def _check_info(info):
@@ -198,7 +198,7 @@ class GaussianProcess(Estimator):
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(n)),), dtype=xd.dtype, device=xd.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, n, self.nb)),), dtype=torch.uint8, device=xd.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=xd.device)
-		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), K.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr())
+		rc = lib.stpy_potrf(dt, n, _lib.ptr(K), _lib.ld(K), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr())
 		_lib.check(rc, "stpy_potrf")
 		del work
 		if defer_check:
@@ -212,7 +212,7 @@ class GaussianProcess(Estimator):
 		scratch = torch.zeros((L.shape[0],), dtype=L.dtype, device=L.device)
 		scratch[:yd.numel()] = yd.reshape(-1)
 		z = torch.empty_like(scratch)
-		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(z), 0,
+		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), _lib.ld(L), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(z), 0,
 								 _lib.stream_ptr()), "stpy_trsv")
 		return z
 
@@ -221,7 +221,7 @@ class GaussianProcess(Estimator):
 		lib = _lib.load()
 		scratch = z.clone()
 		alpha = torch.empty_like(scratch)
-		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(alpha), 1,
+		_lib.check(lib.stpy_trsv(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), _lib.ld(L), _lib.ptr(winv), winv.numel(), _lib.ptr(scratch), _lib.ptr(alpha), 1,
 								 _lib.stream_ptr()), "stpy_trsv")
 		return alpha
 
@@ -261,6 +261,9 @@ class GaussianProcess(Estimator):
 		# the two vector solves are already queued behind the factorisation when the host reads its status (on a matrix that is
 		# not positive definite they ran on garbage and are dropped with the exception: the object stays unfitted)
 		self._check_info(info)
+		# ... and the sticky device word of the one-launch vector solves: a hand-off wait that gave up has poisoned z / alpha
+		# with NaN (stpy_async_status; the stream is already drained by the read above, so this costs one 4-byte copy)
+		_lib.check_async("fit_gp: stpy_trsv")
 		self._L, self._winv, self._z, self._alpha_cache = L, winv, z, alpha
 		self._factor_key = self._hyper_key(self.kernel_object)
 		self.fitted = True
@@ -314,22 +317,21 @@ class GaussianProcess(Estimator):
 		lib = _lib.load()
 		a = self._alpha.reshape(-1).contiguous()
 
-		def dot(u, v):          # <u, v> as a 1 x 1 NT product (the bandwidth-bound row kernel of stpy_gemm_nt)
-			o = torch.empty((1, 1), dtype=u.dtype, device=u.device)
-			_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(u.dtype), 1, 1, u.shape[0], _lib.ptr(u), u.shape[0], _lib.ptr(v), v.shape[0],
-										_lib.ptr(o), 1, 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
-			return o.reshape(())
+		def dot(u, v):          # <u, v> in the fixed-order reduction kernel, read back as a host scalar
+			o = torch.empty((2,), dtype=u.dtype, device=u.device)
+			_lib.check(lib.stpy_trace_dot(_lib.dtype_code(u.dtype), u.shape[0], None, 0, _lib.ptr(u), _lib.ptr(v), _lib.ptr(o), _lib.stream_ptr()), "stpy_trace_dot")
+			return float(o[1].item())
 		if self._Sigma is None:
 			noise = float(self.s) ** 2 * dot(a, a)
 		else:                                   # general noise matrix: alpha^T Sigma^T Sigma alpha = |Sigma alpha|^2
 			Sd = _lib.to_device(self._Sigma, a.dtype).contiguous()
 			v = torch.empty((1, Sd.shape[0]), dtype=a.dtype, device=a.device)
-			_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(a.dtype), 1, Sd.shape[0], Sd.shape[1], _lib.ptr(a), a.shape[0], _lib.ptr(Sd), Sd.stride(0),
-										_lib.ptr(v), v.stride(0), 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
+			_lib.check(lib.stpy_gemm_nt(_lib.dtype_code(a.dtype), 1, Sd.shape[0], Sd.shape[1], _lib.ptr(a), a.shape[0], _lib.ptr(Sd), _lib.ld(Sd),
+										_lib.ptr(v), _lib.ld(v), 0, 0, _lib.stream_ptr()), "stpy_gemm_nt")
 			v = v.reshape(-1)
 			noise = dot(v, v)
 		val = dot(a, self._yd.reshape(-1).contiguous()) - noise
-		return _lib.like_input(torch.sqrt(val).reshape(1, 1), self.x)
+		return _lib.like_input(torch.full((1, 1), math.sqrt(val) if val >= 0 else float("nan"), dtype=a.dtype), self.x)
 
 	def beta(self, delta=1e-3, norm=1):
 		"""gauss_procc.py:186-196: s * norm + sqrt(2 log(1/delta + log(det K / s^n))), K = k(x,x) + s^2 I.
@@ -337,11 +339,12 @@ class GaussianProcess(Estimator):
 		lib = _lib.load()
 		L = self._L
 		out2 = torch.empty((2,), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), None, _lib.ptr(out2),
+		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), _lib.ld(L), None, _lib.ptr(out2),
 										_lib.stream_ptr()), "stpy_logdet_quad")
-		log_ratio = 2.0 * out2[0] - self.n * math.log(float(self.s))
-		val = float(self.s) * norm + torch.sqrt(2.0 * torch.log(1.0 / delta + log_ratio))
-		return _lib.like_input(val.reshape(()), self.x)
+		log_ratio = 2.0 * float(out2[0].item()) - self.n * math.log(float(self.s))          # host scalars from here on
+		arg = 1.0 / delta + log_ratio
+		val = float(self.s) * norm + (math.sqrt(2.0 * math.log(arg)) if arg >= 1.0 else float("nan"))
+		return _lib.like_input(torch.full((), val, dtype=L.dtype), self.x)
 
 	# ------------------------------------------------------------------ prediction
 	def execute(self, xtest):
@@ -379,7 +382,10 @@ class GaussianProcess(Estimator):
 			else:
 				kd = torch.empty((xt.shape[0],), dtype=xt.dtype, device=xt.device)
 				ko._diag_into(xt, kd)
-				yvar = torch.sqrt(kd).reshape(-1, 1)
+				sd = torch.empty_like(kd)           # sqrt(diag K** - 0): the prediction epilogue with no data term
+				_lib.check(lib.stpy_predict_finish(_lib.dtype_code(xt.dtype), xt.shape[0], None, _lib.ptr(torch.zeros_like(kd)), _lib.ptr(kd), 0.0,
+												   _lib.ptr(sd), 0, _lib.stream_ptr()), "stpy_predict_finish")
+				yvar = sd.reshape(-1, 1)
 			zero = torch.zeros((xt.shape[0], 1), dtype=xt.dtype, device=xt.device)
 			return (_lib.like_input(zero, xtest), _lib.like_input(yvar, xtest))
 
@@ -397,22 +403,22 @@ class GaussianProcess(Estimator):
 		if mp > m:
 			X[m:, :].zero_()
 		tw = torch.empty((int(lib.stpy_trsm_workspace_bytes(dt, mp, n, self.nb)),), dtype=torch.uint8, device=X.device)
-		_lib.check(lib.stpy_trsm_right_lt(dt, mp, n, _lib.ptr(self._L), self._L.stride(0), _lib.ptr(self._winv), self._winv.numel(),
-										  _lib.ptr(X), X.stride(0), self.nb, 0, _lib.ptr(tw), tw.numel() * tw.element_size(), st()), "stpy_trsm_right_lt")   # X = K* L^-T
+		_lib.check(lib.stpy_trsm_right_lt(dt, mp, n, _lib.ptr(self._L), _lib.ld(self._L), _lib.ptr(self._winv), self._winv.numel(),
+										  _lib.ptr(X), _lib.ld(X), self.nb, 0, _lib.ptr(tw), tw.numel() * tw.element_size(), st()), "stpy_trsm_right_lt")   # X = K* L^-T
 		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
 		if not full:
 			kd = torch.empty((m,), dtype=xd.dtype, device=xd.device)
 			ko._diag_into(xt, kd)                                       # diag k(x*, x*)           :347
 			sigma = torch.empty((m,), dtype=xd.dtype, device=xd.device)
-			_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(self._z), _lib.ptr(kd), _lib.ptr(mu),
+			_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(X), _lib.ld(X), _lib.ptr(self._z), _lib.ptr(kd), _lib.ptr(mu),
 										_lib.ptr(sigma), 1 if self.clamp_variance else 0, st()), "stpy_predict")
 			return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(sigma.reshape(-1, 1), xtest))
-		_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(self._z), None, _lib.ptr(mu),
+		_lib.check(lib.stpy_predict(dt, m, n, _lib.ptr(X), _lib.ld(X), _lib.ptr(self._z), None, _lib.ptr(mu),
 									None, 0, st()), "stpy_predict")
 		cov = torch.empty((m, m), dtype=xd.dtype, device=xd.device)
 		ko._kernel_into(xt, xt, cov)                                    # K**                      :343
-		_lib.check(lib.stpy_gemm_nt(dt, m, m, n, _lib.ptr(X), X.stride(0), _lib.ptr(X), X.stride(0), _lib.ptr(cov),
-									cov.stride(0), 1, 0, st()), "stpy_gemm_nt")                    # K** - X X^T  :396-399
+		_lib.check(lib.stpy_gemm_nt(dt, m, m, n, _lib.ptr(X), _lib.ld(X), _lib.ptr(X), _lib.ld(X), _lib.ptr(cov),
+									_lib.ld(cov), 1, 0, st()), "stpy_gemm_nt")                    # K** - X X^T  :396-399
 		return (_lib.like_input(mu.reshape(-1, 1), xtest), _lib.like_input(cov, xtest))
 
 	def mean(self, xtest):
@@ -424,7 +430,7 @@ class GaussianProcess(Estimator):
 		Ks = torch.empty((m, n), dtype=xd.dtype, device=xd.device)
 		self.kernel_object._kernel_into(xd, xt, Ks)
 		mu = torch.empty((m,), dtype=xd.dtype, device=xd.device)
-		_lib.check(lib.stpy_predict(_lib.dtype_code(xd.dtype), m, n, _lib.ptr(Ks), Ks.stride(0), _lib.ptr(self._alpha), None,
+		_lib.check(lib.stpy_predict(_lib.dtype_code(xd.dtype), m, n, _lib.ptr(Ks), _lib.ld(Ks), _lib.ptr(self._alpha), None,
 									_lib.ptr(mu), None, 0, _lib.stream_ptr()), "stpy_predict")
 		return _lib.like_input(mu.reshape(-1, 1), xtest)
 
@@ -446,24 +452,29 @@ class GaussianProcess(Estimator):
 			(_, cov) = self.execute(xtest)
 			ymean = self.mu
 			eps = jitter
-		C = _lib.to_device(cov).clone()
-		C.diagonal().add_(eps)
+		cov = _lib.to_device(cov)
+		C = torch.empty_like(cov)
 		dt = _lib.dtype_code(C.dtype)
+		_lib.check(lib.stpy_combine(dt, nn, nn, _lib.ptr(C), _lib.ld(C), _lib.ptr(cov), _lib.ld(cov), _lib.OUT_SET, eps, _lib.stream_ptr()), "stpy_combine")      # C = cov + eps I
 		winv = torch.empty((int(lib.stpy_potrf_winv_elems(nn)),), dtype=C.dtype, device=C.device)
 		work = torch.empty((int(lib.stpy_potrf_workspace_bytes(dt, nn, self.nb)),), dtype=torch.uint8, device=C.device)
 		info = torch.zeros((1,), dtype=torch.int32, device=C.device)
-		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), C.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
+		_lib.check(lib.stpy_potrf(dt, nn, _lib.ptr(C), _lib.ld(C), _lib.ptr(winv), winv.numel(), _lib.ptr(work), work.numel() * work.element_size(), self.nb, 0, _lib.ptr(info), _lib.stream_ptr()), "stpy_potrf")
 		bad = int(info.item())
 		if bad != 0:
 			raise torch.linalg.LinAlgError("sample: posterior covariance + jitter is not positive definite (leading minor %d)" % bad)
-		C.tril_()                                    # the strict upper triangle of an in-place factor is scratch
+		_lib.check(lib.stpy_tril(dt, nn, _lib.ptr(C), _lib.ld(C), _lib.stream_ptr()), "stpy_tril")      # the strict upper triangle of an in-place factor is scratch
 		random_vector = torch.normal(mean=torch.zeros(nn, size, dtype=torch.float64), std=1.)
 		rt = random_vector.T.contiguous().to(device=C.device, dtype=C.dtype)          # (size, nn): the NT operand
+		# f = ymean + L r: the accumulating product on a result that starts as the mean in every column
 		f = torch.empty((nn, size), dtype=C.dtype, device=C.device)
-		_lib.check(lib.stpy_gemm_nt(dt, nn, size, nn, _lib.ptr(C), C.stride(0), _lib.ptr(rt), rt.stride(0), _lib.ptr(f), f.stride(0), 0, 0,
+		if torch.is_tensor(ymean):
+			f.copy_(_lib.to_device(ymean, C.dtype).reshape(nn, 1).expand(nn, size))
+		else:
+			f.fill_(float(ymean))
+		_lib.check(lib.stpy_gemm_nt(dt, nn, size, nn, _lib.ptr(C), _lib.ld(C), _lib.ptr(rt), _lib.ld(rt), _lib.ptr(f), _lib.ld(f), 2, 0,
 									_lib.stream_ptr()), "stpy_gemm_nt")
-		f = _lib.like_input(f, xtest)
-		return ymean + f
+		return _lib.like_input(f, xtest)
 
 	def sample_and_max(self, xtest, size=1):
 		"""gauss_procc.py:484-494."""
@@ -525,11 +536,12 @@ class GaussianProcess(Estimator):
 				self.kernel_object = saved
 			z = self._forward_y(L, winv, self._yd)
 		out2 = torch.empty((2,), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), L.stride(0), _lib.ptr(z), _lib.ptr(out2),
+		_lib.check(lib.stpy_logdet_quad(_lib.dtype_code(L.dtype), L.shape[0], _lib.ptr(L), _lib.ld(L), _lib.ptr(z), _lib.ptr(out2),
 										_lib.stream_ptr()), "stpy_logdet_quad")
 		w = float(weight) if not torch.is_tensor(weight) else float(weight.item())
-		val = 0.5 * out2[1] + 0.5 * w * 2.0 * out2[0]
-		return _lib.like_input(val.reshape(1, 1), self.x), (L, winv, z)
+		logdiag, quad = out2.tolist()                                                   # sum log L_ii, z^T z: host scalars
+		val = torch.full((1, 1), 0.5 * quad + 0.5 * w * 2.0 * logdiag, dtype=L.dtype, device=L.device)
+		return _lib.like_input(val, self.x), (L, winv, z)
 
 	def _log_marginal_grads(self, kernel, X, weight, state, params):
 		"""
@@ -557,11 +569,12 @@ class GaussianProcess(Estimator):
 		alpha = self._backward_z(L, winv, z)[:n]
 		Kinv_p = torch.empty((npad, npad), dtype=L.dtype, device=L.device)
 		work_p = torch.empty((npad, npad), dtype=L.dtype, device=L.device)
-		_lib.check(lib.stpy_potri(dt, npad, _lib.ptr(L), L.stride(0), _lib.ptr(winv), winv.numel(), _lib.ptr(Kinv_p), Kinv_p.stride(0), _lib.ptr(work_p), work_p.numel() * work_p.element_size(), st()), "stpy_potri")
+		_lib.check(lib.stpy_potri(dt, npad, _lib.ptr(L), _lib.ld(L), _lib.ptr(winv), winv.numel(), _lib.ptr(Kinv_p), _lib.ld(Kinv_p), _lib.ptr(work_p), work_p.numel() * work_p.element_size(), st()), "stpy_potri")
 		# inverse of the bordered matrix = [[K^-1, 0], [0, I]]: everything below works on the leading n x n views
 		Kinv, work = Kinv_p[:n, :n], work_p[:n, :n]
-		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), Kinv.stride(0), st()), "stpy_symmetrize_lower")
-		trace_G = w * Kinv.diagonal().sum() - torch.dot(alpha, alpha)                    # tr(w K^-1 - alpha alpha^T)
+		_lib.check(lib.stpy_symmetrize_lower(dt, n, _lib.ptr(Kinv), _lib.ld(Kinv), st()), "stpy_symmetrize_lower")
+		td = torch.empty((2,), dtype=L.dtype, device=L.device)                           # tr(K^-1), alpha^T alpha: fixed-order reduction
+		_lib.check(lib.stpy_trace_dot(dt, n, _lib.ptr(Kinv), _lib.ld(Kinv), _lib.ptr(alpha), _lib.ptr(alpha), _lib.ptr(td), st()), "stpy_trace_dot")
 
 		wanted = [(key, name, t) for (key, name, t) in params if key != "likelihood"]
 		single = len(items) == 1 and len(items[0]['terms']) == 1
@@ -584,8 +597,8 @@ class GaussianProcess(Estimator):
 				# to `work` with K^-1 only read (no N x N copy)
 				H = Kinv if single else work
 				ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
-				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(xd), n, xd.stride(0), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
-											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(Kinv), Kinv.stride(0), _lib.ptr(H), H.stride(0),
+				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(xd), n, _lib.ld(xd), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
+											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(Kinv), _lib.ld(Kinv), _lib.ptr(H), _lib.ld(H),
 											   _lib.ptr(ws), ws.numel() * ws.element_size(), st()), "stpy_lml_weight")
 				# ... o M_i
 				factors = []
@@ -602,25 +615,27 @@ class GaussianProcess(Estimator):
 					if tmp is None:
 						tmp = torch.empty((n, n), dtype=L.dtype, device=L.device)
 					kernel._run_items(fac, xd, xd, tmp)
-					_lib.check(lib.stpy_combine(dt, n, n, _lib.ptr(H), H.stride(0), _lib.ptr(tmp), tmp.stride(0), _lib.OUT_MUL, 0.0, st()), "stpy_combine")
-				xs = (xd if identity else xd[:, group]) * inv_ls                              # scaled coordinates (n, dg)
-				dg = xs.shape[1]
-				XT = torch.cat([xs.T, torch.ones((1, n), dtype=xs.dtype, device=xs.device)]).contiguous()      # (dg + 1, n): NT operand
-				P = torch.empty((n, dg + 1), dtype=xs.dtype, device=xs.device)
-				_lib.check(lib.stpy_gemm_nt(dt, n, dg + 1, n, _lib.ptr(H), H.stride(0), _lib.ptr(XT), XT.stride(0), _lib.ptr(P), P.stride(0), 0, 0, st()), "stpy_gemm_nt")
-				h = P[:, dg]
-				S = (xs * xs * h.unsqueeze(1)).sum(dim=0) - (xs * P[:, :dg]).sum(dim=0)
-				g_ls = S * inv_ls                                                             # d/d(lengthscale) per coordinate of the term
-				acc[(str(i), term['pname'])].index_add_(0, torch.tensor(term['pidx'], device=L.device), g_ls)
+					_lib.check(lib.stpy_combine(dt, n, n, _lib.ptr(H), _lib.ld(H), _lib.ptr(tmp), _lib.ld(tmp), _lib.OUT_MUL, 0.0, st()), "stpy_combine")
+				# [Xs | 1]^T (dg + 1, n): scaled coordinates as the NT operand, then P = H [Xs | 1] and the per-coordinate sums
+				dg = len(group)
+				XT = torch.empty((dg + 1, n), dtype=xd.dtype, device=xd.device)
+				_lib.check(lib.stpy_scaled_points_t(dt, _lib.ptr(xd), n, _lib.ld(xd), dg, _lib.ptr(cols), _lib.ptr(inv_ls), _lib.ptr(XT), _lib.ld(XT), 1, st()), "stpy_scaled_points_t")
+				P = torch.empty((n, dg + 1), dtype=xd.dtype, device=xd.device)
+				_lib.check(lib.stpy_gemm_nt(dt, n, dg + 1, n, _lib.ptr(H), _lib.ld(H), _lib.ptr(XT), _lib.ld(XT), _lib.ptr(P), _lib.ld(P), 0, 0, st()), "stpy_gemm_nt")
+				pidx = _dev_const([int(v) for v in term['pidx']], None, xd.device, int32=True)
+				a_ = acc[(str(i), term['pname'])]
+				_lib.check(lib.stpy_lml_grad_reduce(dt, _lib.ptr(xd), n, _lib.ld(xd), dg, _lib.ptr(cols), _lib.ptr(inv_ls), _lib.ptr(P), _lib.ld(P),
+													_lib.ptr(pidx), _lib.ptr(a_), st()), "stpy_lml_grad_reduce")
 		del work, work_p
 		for key, name, t in wanted:
 			if (key, name) not in acc or int(key) >= len(items) or not any(tm['pname'] == name for tm in items[int(key)]['terms']):
 				raise NotImplementedError("evidence gradient: kernel item %s has no '%s' lengthscale on the device path" % (key, name))
 		grads = []
 		for (key, name, t) in params:
-			if key == "likelihood":      # noise std: dK/ds = 2 s I
+			if key == "likelihood":      # noise std: dK/ds = 2 s I  =>  s tr(w K^-1 - alpha alpha^T), host scalars
 				sval = float(t.detach().reshape(-1)[0].item())
-				g = (sval * trace_G).reshape(t.shape if t.dim() > 0 else ())
+				trK, aa = td.tolist()
+				g = torch.full(t.shape if t.dim() > 0 else (), sval * (w * trK - aa), dtype=L.dtype)
 			else:
 				g = acc[(key, name)].reshape(t.shape if t.dim() > 0 else ())
 			grads.append(g.to(device=t.device, dtype=t.dtype))

@@ -334,6 +334,49 @@ int stpy_symmetrize_lower(int dtype, int64_t n, void* A, int64_t lda, void* stre
 	DISPATCH(dtype, symmetrize_lower<double>(n, (double*)A, lda, st), symmetrize_lower<float>(n, (float*)A, lda, st));
 }
 
+int stpy_tril(int dtype, int64_t n, void* A, int64_t lda, void* stream)
+{
+	if (n <= 0) return 0;
+	if (!A) { set_error("stpy_tril: null pointer"); return -3; }
+	if (lda < n) { set_error("stpy_tril: lda=%lld < n=%lld", (long long)lda, (long long)n); return -4; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype, tril<double>(n, (double*)A, lda, st), tril<float>(n, (float*)A, lda, st));
+}
+
+int stpy_trace_dot(int dtype, int64_t n, const void* A, int64_t lda, const void* u, const void* v, void* out2, void* stream)
+{
+	if (!out2 || (u && !v)) { set_error("stpy_trace_dot: null pointer"); return -7; }
+	if (n < 0 || (A && lda < n)) { set_error("stpy_trace_dot: bad dimensions"); return -4; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         trace_dot<double>(n, (const double*)A, lda, (const double*)u, (const double*)v, (double*)out2, st),
+	         trace_dot<float>(n, (const float*)A, lda, (const float*)u, (const float*)v, (float*)out2, st));
+}
+
+int stpy_scaled_points_t(int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
+                         void* out, int64_t ldo, int ones_row, void* stream)
+{
+	if (n <= 0) return 0;
+	if (!x || !inv_ls || !out) { set_error("stpy_scaled_points_t: null pointer"); return -2; }
+	if (d < 0 || d > 65534 || ldx < 1 || (!cols && ldx < d) || ldo < n) { set_error("stpy_scaled_points_t: bad dimensions"); return -5; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         scaled_points_t<double>((const double*)x, n, ldx, d, cols, (const double*)inv_ls, (double*)out, ldo, ones_row, st),
+	         scaled_points_t<float>((const float*)x, n, ldx, d, cols, (const float*)inv_ls, (float*)out, ldo, ones_row, st));
+}
+
+int stpy_lml_grad_reduce(int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
+                         const void* P, int64_t ldp, const int32_t* pidx, void* acc, void* stream)
+{
+	if (n <= 0 || d <= 0) return 0;
+	if (!x || !inv_ls || !P || !acc) { set_error("stpy_lml_grad_reduce: null pointer"); return -2; }
+	if (ldx < 1 || (!cols && ldx < d) || ldp < d + 1) { set_error("stpy_lml_grad_reduce: bad dimensions"); return -9; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         lml_grad_reduce<double>((const double*)x, n, ldx, d, cols, (const double*)inv_ls, (const double*)P, ldp, pidx, (double*)acc, st),
+	         lml_grad_reduce<float>((const float*)x, n, ldx, d, cols, (const float*)inv_ls, (const float*)P, ldp, pidx, (float*)acc, st));
+}
+
 int64_t stpy_rff_workspace_bytes(int dtype, int64_t n, int d, int64_t m)
 {
 	if (n <= 0 || m <= 0 || d <= 0) return 0;

@@ -151,6 +151,16 @@ template <typename T>
 int logdet_quad(int64_t n, const T* L, int64_t ldl, const T* z, T* out2, hipStream_t st);
 template <typename T>
 int symmetrize_lower(int64_t n, T* A, int64_t lda, hipStream_t st);
+// reduce.hip: small reductions / layout helpers of the evidence gradient, the samplers and the scalar summaries
+template <typename T>
+int tril(int64_t n, T* A, int64_t lda, hipStream_t st);
+template <typename T>
+int trace_dot(int64_t n, const T* A, int64_t lda, const T* u, const T* v, T* out2, hipStream_t st);
+template <typename T>
+int scaled_points_t(const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, T* out, int64_t ldo, int ones_row, hipStream_t st);
+template <typename T>
+int lml_grad_reduce(const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, const T* P, int64_t ldp,
+                    const int32_t* pidx, T* acc, hipStream_t st);
 template <typename T>
 int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, int64_t ldb, int d,
          const int32_t* cols, const T* inv_ls, double kappa, double offset, double diag_add,

@@ -92,7 +92,7 @@ struct GemmArgs {
 };
 #ifdef STPY_STAMPS
 unsigned long long* g_gemm_dbg = nullptr;
-extern "C" void stpy_debug_set_stamp_buffer(void* p) { g_gemm_dbg = (unsigned long long*)p; }
+extern "C" __attribute__((visibility("default"))) void stpy_debug_set_stamp_buffer(void* p) { g_gemm_dbg = (unsigned long long*)p; }
 #endif
 
 // Random-Fourier-feature epilogue: scale * cos(q + b) or scale * sin(q).  fp64: libm-accurate.
@@ -307,7 +307,7 @@ int g_gram_fill = 1;          // stpy_tune route key 28: 1 = the dedicated fp64 
 int gram_fill_f64(int kind, const double* as, const double* bs, const double* na, const double* nb, int dpad, int64_t n, int64_t q,
                   double kappa, double offset, double diag_add, int lower_only, int combine, double* out, int64_t ldo, hipStream_t st)
 {
-	if (!g_gram_fill || combine != STPY_OUT_SET || n % 128 != 0 || q % 128 != 0 || dpad % 16 != 0 || ldo % 2 != 0 || (((uintptr_t)out) & 15) != 0 ||
+	if (!g_gram_fill || combine != STPY_OUT_SET || n % 128 != 0 || q % 128 != 0 || dpad % 16 != 0 || ldo % 2 != 0 || ((((uintptr_t)out) | ((uintptr_t)as) | ((uintptr_t)bs)) & 15) != 0 ||
 	    n >= ((int64_t)1 << 30) || q >= ((int64_t)1 << 30) || (lower_only && n != q)) return 0;
 	if (kind != STPY_K_SE && kind != STPY_K_MATERN32 && kind != STPY_K_MATERN52 && kind != STPY_K_LINEAR) return 0;
 	GramFillArgs p{as, bs, na, nb, out, ldo, dpad, (int)(n / 64), lower_only ? 1 : 0, kappa, kind == STPY_K_LINEAR ? offset : 0.0, diag_add};
@@ -1566,6 +1566,8 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		ksplit = (int)((k + kchunk - 1) / kchunk);          // every pass starts inside [0, k)
 	}
 	if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) { set_error("gemm_nt: dimension exceeds int32"); return -2; }
+	// the tile kernels address C inside a 128-row tile as (unsigned)row * (unsigned)ldc: rows of 2^25 elements or more would wrap
+	if (ldc >= ((int64_t)1 << 25) || ldc2 >= ((int64_t)1 << 25)) { set_error("gemm_nt: leading dimension of C (%lld) must be below 2^25 elements", (long long)(ldc > ldc2 ? ldc : ldc2)); return -10; }
 	GemmArgs<T> p;
 	p.A = A; p.B = B; p.C = C; p.C2 = C2;
 	p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2;

@@ -242,7 +242,8 @@ int gram(int kind, const T* a, int64_t n, int64_t lda, const T* b, int64_t q, in
 // lane where alignment allows.
 template <typename T>
 __global__ __launch_bounds__(256)
-void combine_kernel(T* __restrict__ out, int64_t ldo, const T* __restrict__ src, int64_t lds, int64_t row0, int64_t n, int combine, T diag_add, int vec)
+void combine_kernel(T* out, int64_t ldo, const T* src, int64_t lds,          // (src may be out itself: each element reads its own position)
+                    int64_t row0, int64_t n, int combine, T diag_add, int vec)
 {
 	constexpr int CH = 16 / (int)sizeof(T);
 	typedef T vch __attribute__((ext_vector_type(CH)));

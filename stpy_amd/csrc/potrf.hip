@@ -184,7 +184,7 @@ void potf2_trtri_kernel(T* __restrict__ A, int64_t lda, int nbk, T* __restrict__
 constexpr int SB = 16, NSB = IB / SB, WLD = 17;
 #ifdef STPY_STAMPS
 __device__ unsigned long long* stpy_dbg_potf2 = nullptr;      // diagnostic builds only: [count, pad, 8 stamps x 1000]
-extern "C" void stpy_debug_set_potf2_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(stpy_dbg_potf2), &p, sizeof(p)); }
+extern "C" __attribute__((visibility("default"))) void stpy_debug_set_potf2_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(stpy_dbg_potf2), &p, sizeof(p)); }
 #endif
 constexpr int TRI = IB * (IB + 1) / 2;
 
@@ -252,57 +252,145 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 	// then a second pass for the inverse -- 6.6 us per sub-block, three quarters of the kernel.)
 	auto diag_block = [&](int kb) {
 		const int o = kb * SB;
-		const int q = lane >> 4, i = lane & 15;
-		T a[4], w[4];
+		if constexpr (sizeof(T) == 8) {
+			// fp64 (round 4): block elimination with 4 x 4 pivot blocks on the MFMA.  R = [A | I] (16 x 32) is held as two C/D
+			// fragments (reg r of lane (g, i) = row g + 4r, column i).  Step k:  D = R[4k.., 4k..] (4 x 4) is broadcast through SGPRs and
+			// EVERY lane factors it and inverts the factor in straight-line code (four reciprocal-square-root chains: the only serial
+			// part left); R_k <- inv(L_kk) R_k and R <- R - M R_k are four v_mfma_f64_16x16x4 -- a row block of a C/D fragment IS the B
+			// operand of a rank-4 product, and the normalised block's A part, read as an A operand, IS M = L[:, 4k..4k+3] (masked
+			// below the block).  After four steps the A half holds L^T and the I half inverse(L).  Was: 16 pivots of nine lane permutes
+			// + 8 FMAs each in one dependent chain, 4.9 us per sub-block (8 x 4.9 of the kernel's 57 us).
+			const int i = r16;
+			v4 RA, RW;
 #pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			const int col = 4 * q + c;
-			a[c] = (col <= i) ? S[tri(o + i, o + col)] : T(0);
-			w[c] = (col == i) ? T(1) : T(0);
-		}
-		int first_bad = 0;
-#pragma unroll
-		for (int j = 0; j < SB; ++j) {
-			const int qj = j >> 2, cj = j & 3;
-			T d = bcast(a[cj], 16 * qj + j);
-			// (no branch here: one basic block over all 16 pivots lets the scheduler start the next pivot's reciprocal
-			// square root under the tail of this pivot's update; the failing pivot is reported once, after the loop)
-			const bool bad = !(d > T(0)) || !(d < T(1e300));
-			first_bad = (bad && first_bad == 0) ? j + 1 : first_bad;
-			d = bad ? T(1) : d;
-			// 1/sqrt(d) from the hardware estimate + two Newton steps, l = d * rl (no sqrt + division on the pivot chain)
-			T rl = (T)__builtin_amdgcn_rsq(d);
-			rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
-			rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
-			const T l = d * rl;
-			// scaled column j (meaningful on the lanes of group qj, rows >= j)
-			const T colv = (i == j) ? l : a[cj] * rl;
-			a[cj] = (q == qj && i >= j) ? colv : a[cj];
-			// all nine lane permutes first, then straight-line selects: with `if`s hipcc builds an exec-mask region per
-			// column and waits for each permute on its own
-			const T mi = __shfl(colv, 16 * qj + i, 64);                  // l_ij of this lane's row
-			T lk[4], wj[4];
-#pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				lk[c] = __shfl(colv, 16 * qj + 4 * q + c, 64);           // l_kj of this lane's column k = 4q + c
-				wj[c] = __shfl(w[c], 16 * q + j, 64);                    // pivot row of the inverse
+			for (int r = 0; r < 4; ++r) {
+				const int row = g + 4 * r;
+				RA[r] = (i <= row) ? S[tri(o + row, o + i)] : S[tri(o + i, o + row)];
+				RW[r] = (row == i) ? T(1) : T(0);
 			}
+			int first_bad = 0;
+			const v4 zero4 = v4{0, 0, 0, 0};
 #pragma unroll
-			for (int c = 0; c < 4; ++c) {
-				const int k = 4 * q + c;
-				const T na = a[c] - mi * lk[c];
-				a[c] = (k > j && i >= k) ? na : a[c];
-				const T ws = wj[c] * rl;
-				const T nw = w[c] - mi * ws;
-				w[c] = (i == j) ? ws : ((i > j) ? nw : w[c]);
+			for (int k = 0; k < 4; ++k) {
+				const int c0 = 4 * k;
+				// D[a][b] sits in reg k of lane (a, 4k + b)
+				T d00 = bcast(RA[k], 0 * 16 + c0 + 0);
+				const T d10 = bcast(RA[k], 1 * 16 + c0 + 0), d20 = bcast(RA[k], 2 * 16 + c0 + 0), d30 = bcast(RA[k], 3 * 16 + c0 + 0);
+				T d11 = bcast(RA[k], 1 * 16 + c0 + 1);
+				const T d21 = bcast(RA[k], 2 * 16 + c0 + 1), d31 = bcast(RA[k], 3 * 16 + c0 + 1);
+				T d22 = bcast(RA[k], 2 * 16 + c0 + 2);
+				const T d32 = bcast(RA[k], 3 * 16 + c0 + 2);
+				T d33 = bcast(RA[k], 3 * 16 + c0 + 3);
+				// 1/sqrt(d) from the hardware estimate + two Newton steps; l = d * rl; a failing pivot is replaced by 1 and reported once
+#define STPY_PIVOT(d, rl, jj) \
+				{ const bool bad_ = !(d > T(0)) || !(d < T(1e300)); first_bad = (bad_ && first_bad == 0) ? c0 + jj + 1 : first_bad; d = bad_ ? T(1) : d; } \
+				T rl = (T)__builtin_amdgcn_rsq(d); { const T hd_ = T(0.5) * d; rl = rl * (T(1.5) - hd_ * rl * rl); rl = rl * (T(1.5) - hd_ * rl * rl); }
+				STPY_PIVOT(d00, r0, 0)
+				const T l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+				d11 -= l10 * l10;
+				STPY_PIVOT(d11, r1, 1)
+				const T l21 = (d21 - l20 * l10) * r1, l31 = (d31 - l30 * l10) * r1;
+				d22 -= l20 * l20 + l21 * l21;
+				STPY_PIVOT(d22, r2, 2)
+				const T l32 = (d32 - l30 * l20 - l31 * l21) * r2;
+				d33 -= l30 * l30 + l31 * l31 + l32 * l32;
+				STPY_PIVOT(d33, r3, 3)
+#undef STPY_PIVOT
+				// X = inverse(L_kk), lower 4 x 4 (1 / l_jj = the reciprocal square roots)
+				const T x10 = -r1 * (l10 * r0), x21 = -r2 * (l21 * r1), x32 = -r3 * (l32 * r2);
+				const T x20 = -r2 * (l20 * r0 + l21 * x10), x31 = -r3 * (l31 * r1 + l32 * x21);
+				const T x30 = -r3 * (l30 * r0 + l31 * x10 + l32 * x20);
+				// A operand of X padded to 16 x 4: lane (g, i) holds X[i][g] (i < 4, g <= i), zero elsewhere
+				T xs = T(0);
+				xs = (i == 0 && g == 0) ? r0 : xs;
+				xs = (i == 1 && g == 0) ? x10 : xs;
+				xs = (i == 1 && g == 1) ? r1 : xs;
+				xs = (i == 2 && g == 0) ? x20 : xs;
+				xs = (i == 2 && g == 1) ? x21 : xs;
+				xs = (i == 2 && g == 2) ? r2 : xs;
+				xs = (i == 3 && g == 0) ? x30 : xs;
+				xs = (i == 3 && g == 1) ? x31 : xs;
+				xs = (i == 3 && g == 2) ? x32 : xs;
+				xs = (i == 3 && g == 3) ? r3 : xs;
+				// normalised row block k: rows 0..3 of X_pad * R_k, i.e. reg 0 of the product, lane (g, i) = row g
+				v4 dn0 = MM::mma(xs, RA[k], zero4);
+				v4 dn1 = MM::mma(xs, RW[k], zero4);
+				// Both 8-register results are kept whole and simultaneously live: only element 0 of each is used, and left to itself
+				// hipcc packs the two destination tuples so that they OVERLAP (v[28:35] / v[30:37]) -- two in-flight fp64 MFMAs with
+				// partially overlapping destinations and a constant C are not ordered by the hardware the way the compiler assumes
+				// (measured: rows 4k..4k+3 of a sub-block wrong in ~3 of 128 diagonal blocks, only beside other MFMA traffic).
+				asm volatile("" : "+v"(dn0), "+v"(dn1));
+				const T n0 = dn0[0], n1 = dn1[0];
+				if (k < 3) {
+					// M = L[:, 4k..4k+3] below the block: lane (g, i) needs M[i][g] = (L^T)[4k + g][i] = n0 of this very lane
+					const T mop = (i >= c0 + 4) ? n0 : T(0);
+					RA = MM::mms(mop, n0, RA);
+					RW = MM::mms(mop, n1, RW);
+				}
+				RA[k] = n0;
+				RW[k] = n1;
 			}
-		}
-		if (first_bad != 0 && lane == 0) atomicCAS(info, 0, block_row0 + o + first_bad);
+			if (first_bad != 0 && lane == 0) atomicCAS(info, 0, block_row0 + o + first_bad);
+			// A half = L^T: lane (g, i) reg r = L[i][g + 4r];  I half = inverse(L): reg r = W[g + 4r][i]
 #pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			const int col = 4 * q + c;
-			if (col <= i) S[tri(o + i, o + col)] = a[c];
-			WD[(kb * SB + i) * WLD + col] = (col <= i) ? w[c] : T(0);       // W[row i][col]
+			for (int r = 0; r < 4; ++r) {
+				const int c = g + 4 * r;
+				if (c <= i) S[tri(o + i, o + c)] = RA[r];
+				WD[(kb * SB + c) * WLD + i] = (i <= c) ? RW[r] : T(0);
+			}
+		} else {
+			const int q = lane >> 4, i = lane & 15;
+			T a[4], w[4];
+	#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				a[c] = (col <= i) ? S[tri(o + i, o + col)] : T(0);
+				w[c] = (col == i) ? T(1) : T(0);
+			}
+			int first_bad = 0;
+	#pragma unroll
+			for (int j = 0; j < SB; ++j) {
+				const int qj = j >> 2, cj = j & 3;
+				T d = bcast(a[cj], 16 * qj + j);
+				// (no branch here: one basic block over all 16 pivots lets the scheduler start the next pivot's reciprocal
+				// square root under the tail of this pivot's update; the failing pivot is reported once, after the loop)
+				const bool bad = !(d > T(0)) || !(d < T(1e300));
+				first_bad = (bad && first_bad == 0) ? j + 1 : first_bad;
+				d = bad ? T(1) : d;
+				// 1/sqrt(d) from the hardware estimate + two Newton steps, l = d * rl (no sqrt + division on the pivot chain)
+				T rl = (T)__builtin_amdgcn_rsq(d);
+				rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+				rl = rl * (T(1.5) - T(0.5) * d * rl * rl);
+				const T l = d * rl;
+				// scaled column j (meaningful on the lanes of group qj, rows >= j)
+				const T colv = (i == j) ? l : a[cj] * rl;
+				a[cj] = (q == qj && i >= j) ? colv : a[cj];
+				// all nine lane permutes first, then straight-line selects: with `if`s hipcc builds an exec-mask region per
+				// column and waits for each permute on its own
+				const T mi = __shfl(colv, 16 * qj + i, 64);                  // l_ij of this lane's row
+				T lk[4], wj[4];
+	#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					lk[c] = __shfl(colv, 16 * qj + 4 * q + c, 64);           // l_kj of this lane's column k = 4q + c
+					wj[c] = __shfl(w[c], 16 * q + j, 64);                    // pivot row of the inverse
+				}
+	#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int k = 4 * q + c;
+					const T na = a[c] - mi * lk[c];
+					a[c] = (k > j && i >= k) ? na : a[c];
+					const T ws = wj[c] * rl;
+					const T nw = w[c] - mi * ws;
+					w[c] = (i == j) ? ws : ((i > j) ? nw : w[c]);
+				}
+			}
+			if (first_bad != 0 && lane == 0) atomicCAS(info, 0, block_row0 + o + first_bad);
+	#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const int col = 4 * q + c;
+				if (col <= i) S[tri(o + i, o + col)] = a[c];
+				WD[(kb * SB + i) * WLD + col] = (col <= i) ? w[c] : T(0);       // W[row i][col]
+			}
 		}
 	};
 	// ---- one trailing sub-block (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T  (diagonal sub-blocks: lower part only)

@@ -462,6 +462,80 @@ def main():
 			  [0.7, ag * 1.2], lambda v: {'0': {'gamma': v[0]}, '1': {'ard_gamma': v[1]}})
 	save("G14_lml_grad", x=x, y=y, s=np.array(s14), ard_gamma=ag, groups_flat=np.array([0, -1, 1, 2]), **out)
 
+
+	# ---------------------------------------------------------------- G15: KernelizedFeatures surface (SURVEY section 8f rank 3 + the class's
+	# inherited / auxiliary methods): seeded feature-space samplers (kernelized_features.py:300-336, :537-551), the dual form
+	# (primal=False, n < m: :229-235, :252-254, :285), get_kernel / residuals / logdet_ratio / beta("theory") (:56-106, :553-562).
+	# The draws come from torch's global CPU generator (torch.normal), so the fixture stores the seed AND the draw.
+	rng15 = np.random.RandomState(151)
+	m, d, Ntr, M = 48, 2, 160, 40
+	W = rng15.normal(size=(m, d)) / 0.7
+	x = rng15.uniform(-1, 1, size=(Ntr, d))
+	y = np.cos(2 * x[:, :1]) * x[:, 1:2] + 0.1 * rng15.normal(size=(Ntr, 1))
+	xtest = rng15.uniform(-1, 1, size=(M, d))
+	s15, lam15, kappa15 = 0.25, 1.7, 1.2
+
+	def make_kf(primal=True, beta_fun=None, n=None):
+		emb = RFFEmbedding(gamma=0.7, m=m, d=d, kappa=kappa15)
+		emb.W = T(W)
+		KF = KernelizedFeatures(embedding=emb, m=m, s=s15, lam=lam15, d=d, primal=primal, beta_fun=beta_fun, bound=1.3)
+		nn = Ntr if n is None else n
+		KF.fit_gp(T(x[:nn]), T(y[:nn]))
+		return KF
+
+	out = {}
+	KF = make_kf()
+	for size, seed in ((1, 7), (3, 11)):
+		torch.manual_seed(seed)
+		out["draw_s%d" % size] = N(torch.normal(mean=torch.zeros(size=(m, size), dtype=torch.float64), std=1.))
+		torch.manual_seed(seed)
+		out["theta_post_s%d" % size] = N(KF.sample_theta(size=size))
+		torch.manual_seed(seed)
+		out["theta_prior_s%d" % size] = N(KF.sample_theta(size=size, prior=True))
+		torch.manual_seed(seed)
+		out["f_post_s%d" % size] = N(KF.sample(T(xtest), size=size))
+		torch.manual_seed(seed)
+		out["f_prior_s%d" % size] = N(KF.sample(T(xtest), size=size, prior=True))
+		ko = KernelFunction(kernel_name="squared_exponential", gamma=0.7, kappa=kappa15, d=d)
+		torch.manual_seed(seed)
+		out["f_matheron_s%d" % size] = N(KF.sample_matheron(T(xtest), ko, size=size))
+	torch.manual_seed(23)
+	xm, fm = KF.sample_and_max(T(xtest), size=1)
+	out["max_x"], out["max_f"] = N(xm), N(fm)
+	out["get_kernel_head"] = N(KF.get_kernel()[:6, :6])
+	out["get_kernel_trace"] = np.array(float(torch.trace(KF.get_kernel())))
+	out["residuals"] = N(KF.residuals())
+	out["logdet_ratio_primal"] = N(KF.logdet_ratio())
+	out["beta_default"] = np.array(KF.beta())
+	out["beta_theory_primal"] = N(make_kf(beta_fun="theory").beta(delta=0.2))
+	try:
+		out["effective_dim"] = N(KF.effective_dim(T(xtest)))
+		out["effective_dim_runs"] = np.array(1)
+	except (AttributeError, RuntimeError):    # torch.solve was removed from torch: the reference line raises today
+		out["effective_dim_runs"] = np.array(0)
+	# dual form: n < m
+	nd = 30
+	KD = make_kf(primal=False, n=nd)
+	assert KD.dual is True
+	mu, std = KD.mean_std(T(xtest))
+	th, Z = KD.theta_mean(var=True)
+	out["dual_n"] = np.array(nd)
+	out["dual_mu"], out["dual_std"], out["dual_theta"], out["dual_Z_head"] = N(mu), N(std), N(th), N(Z[:8, :8])
+	out["dual_K_head"] = N(KD.K[:6, :6])
+	out["dual_logdet_ratio"] = N(KD.logdet_ratio())
+	out["dual_invV_head"] = N(KD.get_invV()[:6, :6])
+	torch.manual_seed(31)
+	out["dual_theta_post_s2"] = N(KD.sample_theta(size=2))
+	out["dual_residuals"] = N(KD.residuals())
+	out["dual_beta_theory"] = N(make_kf(primal=False, beta_fun="theory", n=nd).beta(delta=0.2))
+	# primal=False but n >= m stays primal
+	KP = make_kf(primal=False)
+	assert KP.dual is False
+	mu, std = KP.mean_std(T(xtest))
+	out["nondual_mu"], out["nondual_std"] = N(mu), N(std)
+	save("G15_kf_surface", W=W, x=x, y=y, xtest=xtest, gamma=np.array(0.7), kappa=np.array(kappa15), s=np.array(s15), lam=np.array(lam15),
+		 bound=np.array(1.3), **out)
+
 	# ---------------------------------------------------------------- B1: beta() and norm() (gauss_procc.py:179-196)
 	rng3 = np.random.RandomState(20241103)
 	x = rng3.uniform(-1, 1, size=(14, 2)); y = np.sin(x.sum(axis=1, keepdims=True)) + 0.05 * rng3.normal(size=(14, 1))

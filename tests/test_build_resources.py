@@ -198,3 +198,26 @@ def test_round3_kernels_keep_their_occupancy(tmp_path):
 		assert get(b, r"Occupancy \[waves/SIMD\]") >= (4 if fast else 3), n
 		assert get(b, r"ScratchSize \[bytes/lane\]") == 0, n
 		assert get(b, r"LDS Size \[bytes/block\]") <= 40 * 1024, n
+
+
+def test_diag_block_kernel_has_no_overlapping_mfma_destinations(tmp_path):
+	"""potf2_trtri_mfma_kernel<double>: two v_mfma_f64_16x16x4 with a constant C (results of which only element 0 is used) must not
+	be given partially overlapping destination tuples -- hipcc packs them that way when the unused elements are dead, and the
+	hardware does not order the element writes of two such instructions in flight (wrong rows in ~3 of 128 diagonal blocks beside
+	other MFMA traffic; tools/factor_stress.py).  The kernel pins both results whole with an asm keep-alive; this checks the ISA."""
+	asm = tmp_path / "potrf.s"
+	subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-S", "--cuda-device-only",
+					os.path.join(CSRC, "potrf.hip"), "-o", str(asm)], check=True, capture_output=True)
+	lines = asm.read_text().splitlines()
+	start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4stpy23potf2_trtri_mfma_kernelIdEE"))
+	end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+	pat = re.compile(r"v_mfma_f64_16x16x4_f64 v\[(\d+):(\d+)\], v\[\d+:\d+\], v\[\d+:\d+\], (\S+)")
+	mf = []
+	for l in lines[start:end]:
+		m = pat.search(l)
+		if m:
+			mf.append((int(m.group(1)), int(m.group(2)), m.group(3)))
+	assert len(mf) > 20
+	for (a0, a1, _), (b0, b1, cb) in zip(mf, mf[1:]):
+		if cb == "0" and (a0, a1) != (b0, b1):
+			assert b1 < a0 or b0 > a1, "consecutive MFMAs write overlapping tuples v[%d:%d] / v[%d:%d]" % (a0, a1, b0, b1)

@@ -33,3 +33,13 @@ def test_random_factor_solve_sweep():
 	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_factor.py"), "60", "4"], cwd=ROOT, capture_output=True, text=True, timeout=600)
 	assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 	assert "all 60 factor / solve cases passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_factor_stress_every_block_every_time():
+	"""tools/factor_stress.py: eight factorisations of the same N = 8192 matrix, L L^T - K and W L - I checked for EVERY 128-block each
+	time.  Round 4's MFMA diagonal-block kernel once produced a wrong 4-row group in ~3 of 128 diagonal blocks, only beside the
+	trailing update's MFMA traffic and not in every run (two fp64 MFMAs in flight with partially overlapping destination registers);
+	sampled-row checks and the small-size kernel tests all passed."""
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "factor_stress.py"), "8192", "8", "8"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0 and "STRESS ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

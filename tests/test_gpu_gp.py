@@ -22,6 +22,10 @@ def S(gpu_device):
 	return stpy_amd
 
 
+def se_spec(gamma, kappa=1.0, group=None):
+	return [("squared_exponential", {"gamma": float(gamma), "kappa": float(kappa), "group": group}, "-")]
+
+
 def T(a, cuda=False):
 	t = torch.from_numpy(np.ascontiguousarray(a)).double()
 	return t.cuda() if cuda else t
@@ -617,10 +621,138 @@ def test_G12_kernelized_features(S):
 		assert rel_err(N(KF.V)[:8, :8], g["V_head"]) < 1e-12
 		kk = KF.kernel(T(g["x"][:5], cuda), T(g["x"][:7], cuda))
 		assert tuple(kk.shape) == (7, 5) and rel_err(N(kk), g["kernel_head"]) < 1e-12
+	# queued points (kernelized_features.py:108-113): nothing is refactored until the next prediction folds them in
 	KF.add_data_point(T(g["x"][:3], True), T(g["y"][:3], True))        # (KF holds cuda data after the loop)
-	assert KF.n == g["x"].shape[0] + 3
-	with pytest.raises(NotImplementedError):
-		KernelizedFeatures(embedding=emb, m=m, primal=False)
+	KF.add_data_point(T(g["x"][3:5], True), T(g["y"][3:5], True))
+	assert KF.fitted is False and len(KF.to_add) == 2 and KF.n == g["x"].shape[0]
+	mu, std = KF.mean_std(T(g["xtest"], True))
+	assert KF.fitted is True and KF.to_add == [] and KF.n == g["x"].shape[0] + 5
+	xx, yy = np.concatenate([g["x"], g["x"][:5]]), np.concatenate([g["y"], g["y"][:5]])
+	Q = O.rff_embed(xx, g["W"], m, kappa=1.5)
+	_, invV, theta = O.kernelized_features_fit(Q, yy, 0.2, 1.3)
+	mu_o, std_o = O.kernelized_features_mean_std(O.rff_embed(g["xtest"], g["W"], m, kappa=1.5), invV, theta, 0.2)
+	assert rel_err(N(mu), mu_o) < TOL and rel_err(N(std), std_o) < TOL
+
+
+def _kf15(S, g, cuda, primal=True, beta_fun=None, n=None):
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	m, d = g["W"].shape
+	emb = S.RFFEmbedding(gamma=float(g["gamma"]), m=m, d=d, kappa=float(g["kappa"]))
+	emb.W = T(g["W"])
+	KF = KernelizedFeatures(embedding=emb, m=m, s=float(g["s"]), lam=float(g["lam"]), d=d, primal=primal, beta_fun=beta_fun, bound=float(g["bound"]))
+	nn = g["x"].shape[0] if n is None else n
+	KF.fit_gp(T(g["x"][:nn], cuda), T(g["y"][:nn], cuda))
+	return KF
+
+
+def test_G15_feature_space_sampling(S):
+	"""sample_theta / sample / sample_matheron / sample_and_max (kernelized_features.py:300-336, :537-551) with the
+	reference's seeded CPU-generator draws, against the imported reference."""
+	g = golden("G15_kf_surface")
+	for cuda in (False, True):
+		KF = _kf15(S, g, cuda)
+		assert isinstance(KF, S.GaussianProcess)
+		for size, seed in ((1, 7), (3, 11)):
+			torch.manual_seed(seed)
+			th = KF.sample_theta(size=size)
+			assert tuple(th.shape) == g["theta_post_s%d" % size].shape and th.is_cuda == cuda
+			assert rel_err(N(th), g["theta_post_s%d" % size]) < TOL
+			torch.manual_seed(seed)
+			assert rel_err(N(KF.sample_theta(size=size, prior=True)), g["theta_prior_s%d" % size]) < 1e-14
+			torch.manual_seed(seed)
+			f = KF.sample(T(g["xtest"], cuda), size=size)
+			assert tuple(f.shape) == g["f_post_s%d" % size].shape and rel_err(N(f), g["f_post_s%d" % size]) < TOL
+			torch.manual_seed(seed)
+			assert rel_err(N(KF.sample(T(g["xtest"], cuda), size=size, prior=True)), g["f_prior_s%d" % size]) < 1e-12
+			ko = S.KernelFunction(kernel_name="squared_exponential", gamma=float(g["gamma"]), kappa=float(g["kappa"]), d=g["W"].shape[1])
+			torch.manual_seed(seed)
+			fm = KF.sample_matheron(T(g["xtest"], cuda), ko, size=size)
+			assert tuple(fm.shape) == g["f_matheron_s%d" % size].shape and rel_err(N(fm), g["f_matheron_s%d" % size]) < TOL
+		torch.manual_seed(23)
+		xm, fmax = KF.sample_and_max(T(g["xtest"], cuda), size=1)
+		assert rel_err(N(xm), g["max_x"]) < 1e-15 and rel_err(N(fmax), g["max_f"]) < TOL
+	# an unfitted object samples the prior (kernelized_features.py:331-334)
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	m, d = g["W"].shape
+	emb = S.RFFEmbedding(gamma=0.7, m=m, d=d)
+	emb.W = T(g["W"])
+	K0 = KernelizedFeatures(embedding=emb, m=m, s=0.1, lam=float(g["lam"]), d=d)
+	torch.manual_seed(7)
+	assert rel_err(N(K0.sample_theta(size=1)), g["theta_prior_s1"]) < 1e-14
+
+
+def test_G15_kernelized_features_surface_and_dual(S):
+	"""get_kernel / residuals / logdet_ratio / beta / effective_dim and the dual form (primal=False, n < m) of KernelizedFeatures
+	(kernelized_features.py:56-106, :164-174, :229-235, :252-254, :285, :553-562) against the imported reference."""
+	g = golden("G15_kf_surface")
+	m = g["W"].shape[0]
+	s, lam, kappa = float(g["s"]), float(g["lam"]), float(g["kappa"])
+	for cuda in (False, True):
+		KF = _kf15(S, g, cuda)
+		Kk = KF.get_kernel()
+		assert rel_err(N(Kk)[:6, :6], g["get_kernel_head"]) < 1e-12 and abs(float(torch.trace(Kk)) - g["get_kernel_trace"]) / g["get_kernel_trace"] < 1e-12
+		assert abs(float(KF.residuals()) - g["residuals"]) / g["residuals"] < TOL
+		assert abs(float(KF.logdet_ratio()) - g["logdet_ratio_primal"]) < 1e-10
+		assert KF.beta() == 2.0 and tuple(KF.K.shape) == (1, 1)
+		assert abs(float(_kf15(S, g, cuda, beta_fun="theory").beta(delta=0.2)) - g["beta_theory_primal"]) / abs(g["beta_theory_primal"]) < TOL
+		ed = float(KF.effective_dim(T(g["xtest"], cuda)))
+		assert abs(ed - O.kernelized_features_effective_dim(O.rff_embed(g["xtest"], g["W"], m, kappa=kappa), lam)) / ed < TOL
+		# dual form
+		nd = int(g["dual_n"])
+		KD = _kf15(S, g, cuda, primal=False, n=nd)
+		assert KD.dual is True
+		mu, std = KD.mean_std(T(g["xtest"], cuda))
+		assert mu.is_cuda == cuda and rel_err(N(mu), g["dual_mu"]) < TOL and rel_err(N(std), g["dual_std"]) < TOL
+		th, Z = KD.theta_mean(var=True)
+		assert rel_err(N(th), g["dual_theta"]) < TOL and rel_err(N(Z)[:8, :8], g["dual_Z_head"]) < 1e-7
+		assert rel_err(N(KD.K)[:6, :6], g["dual_K_head"]) < 1e-12
+		assert abs(float(KD.logdet_ratio()) - g["dual_logdet_ratio"]) / abs(g["dual_logdet_ratio"]) < TOL
+		assert rel_err(N(KD.get_invV())[:6, :6], g["dual_invV_head"]) < 1e-8
+		torch.manual_seed(31)
+		assert rel_err(N(KD.sample_theta(size=2)), g["dual_theta_post_s2"]) < TOL
+		assert abs(float(KD.residuals()) - g["dual_residuals"]) / g["dual_residuals"] < 1e-6
+		assert abs(float(_kf15(S, g, cuda, primal=False, beta_fun="theory", n=nd).beta(delta=0.2)) - g["dual_beta_theory"]) / abs(g["dual_beta_theory"]) < TOL
+		# dual + queued points: refit on the concatenated data; reaching n >= m converts to the primal form (check_conversion)
+		KD.add_data_point(T(g["x"][nd:nd + 4], cuda), T(g["y"][nd:nd + 4], cuda))
+		mu, std = KD.mean_std(T(g["xtest"], cuda))
+		Q = O.rff_embed(g["x"][:nd + 4], g["W"], m, kappa=kappa)
+		_, invK_V, thd = O.kernelized_features_dual_fit(Q, g["y"][:nd + 4], s, lam)
+		mu_o, std_o = O.kernelized_features_dual_mean_std(O.rff_embed(g["xtest"], g["W"], m, kappa=kappa), invK_V, thd)
+		assert KD.dual is True and rel_err(N(mu), mu_o) < TOL and rel_err(N(std), std_o) < TOL
+		KD.add_data_point(T(g["x"][nd + 4:m + 6], cuda), T(g["y"][nd + 4:m + 6], cuda))
+		mu, _ = KD.mean_std(T(g["xtest"], cuda))
+		assert KD.dual is False and KD.n == m + 6
+		# primal=False with n >= m is the primal path
+		KP = _kf15(S, g, cuda, primal=False)
+		assert KP.dual is False
+		mu, std = KP.mean_std(T(g["xtest"], cuda))
+		assert rel_err(N(mu), g["nondual_mu"]) < TOL and rel_err(N(std), g["nondual_std"]) < TOL
+
+
+def test_kernelized_features_inherits_evidence_and_search(S):
+	"""KernelizedFeatures derives from GaussianProcess (kernelized_features.py:12): log_marginal(kernel, X, weight) is the evidence of
+	``kernel`` on the stored data (gauss_procc.py:631-638), with its gradient; optimize_params works once a kernel_object is attached."""
+	g = golden("G15_kf_surface")
+	KF = _kf15(S, g, False)
+	d = g["W"].shape[1]
+	ko = S.KernelFunction(kernel_name="squared_exponential", gamma=0.9, kappa=float(g["kappa"]), d=d)
+	spec = se_spec(0.9, float(g["kappa"]))
+	val = KF.log_marginal(ko, {}, 1.0)
+	assert tuple(val.shape) == (1, 1)
+	ref = O.log_marginal(g["x"], g["y"], spec, float(g["s"]))
+	assert abs(float(val) - ref) / abs(ref) < TOL
+	gam = torch.tensor([0.6], dtype=torch.float64, requires_grad=True)
+	v = KF.log_marginal(ko, {'0': {'gamma': gam}}, 0.5)
+	v.backward()
+	_, gref, _ = O.log_marginal_grad(g["x"], g["y"], se_spec(0.6, float(g["kappa"])), float(g["s"]), weight=0.5)
+	assert abs(float(gam.grad) - gref[0]["gamma"][0]) / abs(gref[0]["gamma"][0]) < 1e-7
+	with pytest.raises(AttributeError):
+		KF.optimize_params(type="bandwidth", restarts=1)          # no kernel_object: as in the reference
+	KF.kernel_object = ko
+	assert KF.optimize_params(type="bandwidth", restarts=1, optimizer="pytorch-minimize", maxiter=20, init_func=lambda k: torch.tensor([0.9], dtype=torch.float64)) is True
+	g_opt = float(ko.params_dict['0']['gamma'].reshape(-1)[0])
+	best = float(KF.log_marginal(ko, {}, 1.0))
+	assert best <= float(val) + 1e-9 and g_opt > 0 and KF.fitted is True
 
 
 def test_B1_beta_norm_bounds(S):
@@ -1063,8 +1195,9 @@ def test_kernelized_features_add_data_point_extends_the_normal_equations(S):
 	KF.add_data_point(T(x[:1000], True), T(y[:1000], True))          # first call = fit
 	KF.add_data_point(T(x[1000:1003], True), T(y[1000:1003], True))   # a handful of rows
 	KF.add_data_point(T(x[1003:], True), T(y[1003:], True))
-	assert KF.n == n and tuple(KF.x.shape) == (n, d)
+	assert KF.fitted is False and len(KF.to_add) == 2          # queued as in the reference (:108-113), folded in by the next prediction
 	mu, std = KF.mean_std(T(xt, True))
+	assert KF.n == n and tuple(KF.x.shape) == (n, d) and KF.fitted is True and KF.to_add == []
 	KF2 = KernelizedFeatures(embedding=emb, m=m, s=0.2, lam=1.0, d=d)
 	KF2.fit_gp(T(x, True), T(y, True))
 	mu2, std2 = KF2.mean_std(T(xt, True))

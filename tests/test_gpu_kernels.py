@@ -1087,3 +1087,96 @@ def test_trsv_handoff_timeout_is_loud(L):
 	L.check(lib.stpy_trsv(L.F64, n, L.ptr(Ld), n, L.ptr(winv), winv.numel(), L.ptr(yd), L.ptr(zd), 0, L.stream_ptr()), "trsv")
 	assert lib.stpy_async_status(L.stream_ptr()) == 0
 	assert rel_err(zd.cpu().numpy(), sla.solve_triangular(np.linalg.cholesky(K), y, lower=True)) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------ small reductions / layout helpers (reduce.hip)
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-14), (torch.float32, 1e-6)])
+@pytest.mark.parametrize("n", [1, 63, 64, 130, 1000])
+def test_tril_trace_dot(L, dtype, tol, n):
+	lib = L.load()
+	rng = np.random.RandomState(n)
+	code = L.dtype_code(dtype)
+	ld = n + 3
+	A = rng.normal(size=(n, ld))
+	Ad = dev(A, dtype)
+	u, v = rng.normal(size=n), rng.normal(size=n)
+	ud, vd = dev(u, dtype), dev(v, dtype)
+	out = torch.full((2,), float("nan"), dtype=dtype, device="cuda:0")
+	L.check(lib.stpy_trace_dot(code, n, L.ptr(Ad), ld, L.ptr(ud), L.ptr(vd), L.ptr(out), L.stream_ptr()), "trace_dot")
+	o = out.cpu().numpy().astype(np.float64)
+	scale = np.abs(np.diag(A[:, :n])).sum() + 1
+	assert abs(o[0] - np.trace(A[:, :n])) / scale < tol * 10 and abs(o[1] - u @ v) / (np.abs(u * v).sum() + 1) < tol * 10
+	L.check(lib.stpy_trace_dot(code, n, None, 0, None, None, L.ptr(out), L.stream_ptr()), "trace_dot")
+	assert out.cpu().tolist() == [0.0, 0.0]
+	L.check(lib.stpy_tril(code, n, L.ptr(Ad), ld, L.stream_ptr()), "tril")
+	got = Ad.cpu().numpy().astype(np.float64)
+	ref = A.astype(np.float32 if dtype == torch.float32 else np.float64).astype(np.float64)
+	ref[:, :n] = np.tril(ref[:, :n])
+	assert np.array_equal(got, ref)          # (the padding columns beyond n are untouched)
+	assert lib.stpy_tril(code, n, L.ptr(Ad), n - 1, L.stream_ptr()) == -4 if n > 1 else True
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-4)])
+def test_scaled_points_and_lml_grad_reduce(L, dtype, tol):
+	"""stpy_scaled_points_t builds [Xs | 1]^T; stpy_lml_grad_reduce turns P = H [Xs | 1] into the per-parameter sums
+	inv_ls_k/2 sum_ij H_ij (xs_ik - xs_jk)^2 accumulated at acc[pidx[k]] (checked against that double sum directly)."""
+	lib = L.load()
+	rng = np.random.RandomState(3)
+	code = L.dtype_code(dtype)
+	n, dfull = 700, 6
+	cols = [4, 0, 2]
+	inv = np.array([0.7, 1.9, 0.4])
+	x = rng.uniform(-1, 1, size=(n, dfull))
+	xd = dev(x, dtype)
+	for use_cols in (True, False):
+		c = cols if use_cols else [0, 1, 2]
+		d = len(c)
+		cd = torch.tensor(c, dtype=torch.int32, device="cuda:0") if use_cols else None
+		invd = dev(inv, dtype)
+		XT = torch.full((d + 1, n + 5), float("nan"), dtype=dtype, device="cuda:0")
+		L.check(lib.stpy_scaled_points_t(code, L.ptr(xd), n, dfull, d, L.ptr(cd), L.ptr(invd), L.ptr(XT), n + 5, 1, L.stream_ptr()), "scaled_points_t")
+		xs = x[:, c] * inv
+		got = XT.cpu().numpy().astype(np.float64)
+		assert rel_err(got[:d, :n], xs.T) < (1e-15 if dtype == torch.float64 else 1e-7) and np.all(got[d, :n] == 1.0) and np.isnan(got[:, n:]).all()
+		H = rng.normal(size=(n, n)); H = H + H.T
+		P = H @ np.concatenate([xs, np.ones((n, 1))], axis=1)
+		pidx = [1, 0, 1]
+		acc0 = np.array([0.25, -1.5])
+		acc = dev(acc0, dtype)
+		Pd, pd = dev(P, dtype), torch.tensor(pidx, dtype=torch.int32, device="cuda:0")
+		L.check(lib.stpy_lml_grad_reduce(code, L.ptr(xd), n, dfull, d, L.ptr(cd), L.ptr(invd), L.ptr(Pd), d + 1, L.ptr(pd), L.ptr(acc), L.stream_ptr()), "lml_grad_reduce")
+		ref = acc0.copy()
+		for k in range(d):
+			diff = xs[:, k:k + 1] - xs[:, k:k + 1].T
+			ref[pidx[k]] += inv[k] * 0.5 * np.sum(H * diff * diff)
+		scale = np.abs(H).sum()
+		assert np.max(np.abs(acc.cpu().numpy().astype(np.float64) - ref)) / scale < tol
+
+
+def test_async_status_raises_through_the_classes(L, monkeypatch):
+	"""A non-zero stpy_async_status (a hand-off wait of the one-launch vector solve that gave up: NaN results) must surface as an
+	exception from GaussianProcess.fit_gp and KernelizedFeatures.fit_gp, and leave the object unfitted.  The product library has no
+	fault hook, so the status word is stubbed on the host side; the device-side fault itself is covered by
+	test_trsv_handoff_timeout_is_loud on the lab build."""
+	import stpy_amd
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	lib = L.load()
+	rng = np.random.RandomState(0)
+	x = torch.from_numpy(rng.uniform(-1, 1, size=(300, 2)))
+	y = torch.from_numpy(np.sin(x.numpy().sum(axis=1, keepdims=True)))
+	GP = stpy_amd.GaussianProcess(gamma=0.5, s=0.1, kernel_name="squared_exponential", d=2)
+	GP.fit_gp(x, y)
+	assert GP.fitted
+	monkeypatch.setattr(lib, "stpy_async_status", lambda stream: 1)
+	with pytest.raises(L.StpyHipError, match="stpy_async_status"):
+		GP.fit_gp(x, y)
+	assert GP.fitted is False
+	emb = stpy_amd.RFFEmbedding(gamma=0.5, m=32, d=2)
+	KF = KernelizedFeatures(embedding=emb, m=32, s=0.1, d=2)
+	with pytest.raises(L.StpyHipError, match="stpy_async_status"):
+		KF.fit_gp(x, y)
+	assert KF.fitted is False
+	monkeypatch.undo()
+	KF.fit_gp(x, y)
+	GP.fit_gp(x, y)
+	assert KF.fitted and GP.fitted

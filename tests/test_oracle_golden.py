@@ -3,6 +3,7 @@ Pins the CPU oracle (oracle/gp_oracle.py) against the golden vectors captured fr
 reference (tests/golden/make_golden.py).  CPU only.
 """
 import numpy as np
+import torch
 import pytest
 
 from oracle import gp_oracle as O
@@ -279,6 +280,61 @@ def test_G12_kernelized_features():
 	# reference quirk: KernelizedFeatures.kernel goes through KernelFunction(kernel_name="linear") built with the
 	# default d=1, i.e. group=[0] (kernelized_features.py:49) -> only the FIRST feature column enters
 	assert rel_err(O.linear(Qa, Qb, group=[0]), g["kernel_head"]) < 1e-13 and g["kernel_head"].shape == (7, 5)
+
+
+def test_G15_kernelized_features_surface():
+	"""Feature-space samplers, dual form and the auxiliary methods of KernelizedFeatures (kernelized_features.py:56-106, :164-174,
+	:229-235, :300-336, :537-562) against the imported reference."""
+	g = golden("G15_kf_surface")
+	m = g["W"].shape[0]
+	s, lam, kappa, bound = float(g["s"]), float(g["lam"]), float(g["kappa"]), float(g["bound"])
+	Q = O.rff_embed(g["x"], g["W"], m, kappa=kappa)
+	Qt = O.rff_embed(g["xtest"], g["W"], m, kappa=kappa)
+	V, invV, theta = O.kernelized_features_fit(Q, g["y"], s, lam)
+	spec = se_spec(g["gamma"], g["kappa"])
+	for size in (1, 3):
+		r = g["draw_s%d" % size]
+		th = O.kernelized_features_sample_theta(theta, invV, s, r)
+		assert rel_err(th, g["theta_post_s%d" % size]) < 1e-8
+		assert rel_err(Qt @ th, g["f_post_s%d" % size]) < 1e-8
+		thp = O.kernelized_features_prior_theta(lam, r)
+		assert rel_err(thp, g["theta_prior_s%d" % size]) < 1e-14
+		assert rel_err(Qt @ thp, g["f_prior_s%d" % size]) < 1e-13
+		f = O.kernelized_features_sample_matheron(Q, Qt, g["y"], O.kernel(g["x"], g["xtest"], spec), O.kernel(g["x"], g["x"], spec), s, lam, r)
+		assert rel_err(f, g["f_matheron_s%d" % size]) < 1e-8
+	Kq = O.kernelized_features_first_feature_kernel(Q, Q, s ** 2 * lam)
+	assert rel_err(Kq[:6, :6], g["get_kernel_head"]) < 1e-13 and abs(np.trace(Kq) - g["get_kernel_trace"]) / g["get_kernel_trace"] < 1e-13
+	mu, _ = O.kernelized_features_mean_std(Q, invV, theta, s)
+	assert abs(np.sum((mu - g["y"]) ** 2) - g["residuals"]) / g["residuals"] < 1e-9
+	assert abs(O.kernelized_features_logdet_ratio(np.ones((1, 1)), s, lam, m) - g["logdet_ratio_primal"]) < 1e-12
+	assert g["beta_default"] == 2.0
+	assert abs(O.kernelized_features_beta_theory(Q, s, lam, bound, 0.2) - g["beta_theory_primal"]) / abs(g["beta_theory_primal"]) < 1e-12
+	assert int(g["effective_dim_runs"]) == 0          # the reference line calls the removed torch.solve: the oracle restates its formula
+	ed = O.kernelized_features_effective_dim(Qt, lam)
+	assert 0 < ed < min(m, Qt.shape[0])
+	# dual form
+	nd = int(g["dual_n"])
+	Qd = Q[:nd]
+	K, invK_V, thd = O.kernelized_features_dual_fit(Qd, g["y"][:nd], s, lam)
+	mu, std = O.kernelized_features_dual_mean_std(Qt, invK_V, thd)
+	assert rel_err(mu, g["dual_mu"]) < 1e-9 and rel_err(std, g["dual_std"]) < 1e-9
+	assert rel_err(thd, g["dual_theta"]) < 1e-9 and rel_err(invK_V[:8, :8], g["dual_Z_head"]) < 1e-9
+	assert rel_err(K[:6, :6], g["dual_K_head"]) < 1e-13
+	assert abs(O.kernelized_features_logdet_ratio(K, s, lam, m) - g["dual_logdet_ratio"]) / abs(g["dual_logdet_ratio"]) < 1e-12
+	invVq = O.kernelized_features_dual_get_invV(Qd, s, lam)
+	assert rel_err(invVq[:6, :6], g["dual_invV_head"]) < 1e-10
+	torch.manual_seed(31)
+	r = torch.normal(mean=torch.zeros(size=(m, 2), dtype=torch.float64), std=1.).numpy()
+	assert rel_err(O.kernelized_features_sample_theta(thd, invVq, s, r), g["dual_theta_post_s2"]) < 1e-8
+	mud, _ = O.kernelized_features_dual_mean_std(Qd, invK_V, thd)
+	assert abs(np.sum((mud - g["y"][:nd]) ** 2) - g["dual_residuals"]) / g["dual_residuals"] < 1e-8
+	assert abs(O.kernelized_features_beta_theory(Qd, s, lam, bound, 0.2) - g["dual_beta_theory"]) / abs(g["dual_beta_theory"]) < 1e-12
+	# primal=False with n >= m stays primal
+	mu, std = O.kernelized_features_mean_std(Qt, invV, theta, s)
+	assert rel_err(mu, g["nondual_mu"]) < 1e-9 and rel_err(std, g["nondual_std"]) < 1e-9
+	# the seeded draw itself is reproducible from the stored seed
+	torch.manual_seed(7)
+	assert np.array_equal(torch.normal(mean=torch.zeros(size=(m, 1), dtype=torch.float64), std=1.).numpy(), g["draw_s1"])
 
 
 def test_B1_beta_norm():

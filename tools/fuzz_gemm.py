@@ -15,6 +15,7 @@ lib = L.load()
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+torch.manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)          # the operands come from the device generator: seeded, so a run is reproducible
 DIMS = [1, 2, 3, 7, 8, 9, 16, 31, 64, 100, 127, 128, 129, 255, 256, 384, 500, 512, 640, 1000, 1024, 1152, 2048, 2500]
 KS = [1, 2, 4, 7, 16, 32, 33, 64, 100, 128, 129, 256, 512, 1000, 1024, 2048]
 for case in range(cases):
@@ -48,7 +49,9 @@ for case in range(cases):
 			msk = ti[:, None] >= ti[None, :]
 			assert torch.equal(C[:, :n][~msk], C0[:, :n][~msk]), "a tile above the diagonal was written"
 			err = err[msk]
-		tol = 4e-15 if dt == torch.float64 else 3e-6
+		# fp64: the diagonal of A A^T (same-operand lower-only cases) sums K positive terms, whose rounding walks to ~sqrt(K) eps/2 of the sum in
+		# BOTH results -- tools/gemm_err_probe.py at K = 2048: kernel vs float128 3.5e-15, torch matmul vs float128 4.4e-15, kernel vs torch 3.2e-15
+		tol = 1.2e-14 if dt == torch.float64 else 3e-6
 		assert float(err.max()) < tol, (float(err.max()), tol)
 		if pc:
 			assert bool((C[:, n:] == 7.0).all()), "padding of C written"
