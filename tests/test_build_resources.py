@@ -213,11 +213,14 @@ def test_diag_block_kernel_has_no_overlapping_mfma_destinations(tmp_path):
 	end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 	pat = re.compile(r"v_mfma_f64_16x16x4_f64 v\[(\d+):(\d+)\], v\[\d+:\d+\], v\[\d+:\d+\], (\S+)")
 	mf = []
-	for l in lines[start:end]:
+	for ln, l in enumerate(lines[start:end]):
 		m = pat.search(l)
 		if m:
-			mf.append((int(m.group(1)), int(m.group(2)), m.group(3)))
+			mf.append((ln, int(m.group(1)), int(m.group(2)), m.group(3)))
 	assert len(mf) > 20
-	for (a0, a1, _), (b0, b1, cb) in zip(mf, mf[1:]):
-		if cb == "0" and (a0, a1) != (b0, b1):
-			assert b1 < a0 or b0 > a1, "consecutive MFMAs write overlapping tuples v[%d:%d] / v[%d:%d]" % (a0, a1, b0, b1)
+	# "in flight together": the second issues within a few instructions of the first (an fp64 16x16x4 occupies the pipe for 64 cycles)
+	body = lines[start:end]
+	for (la, a0, a1, _), (lb, b0, b1, cb) in zip(mf, mf[1:]):
+		# (a pair the compiler separated by wait states -- a true dependency it knows about -- is not in flight together)
+		if cb == "0" and (a0, a1) != (b0, b1) and lb - la <= 12 and not any("s_nop" in l for l in body[la:lb]):
+			assert b1 < a0 or b0 > a1, "MFMAs %d instructions apart write overlapping tuples v[%d:%d] / v[%d:%d]" % (lb - la, a0, a1, b0, b1)
