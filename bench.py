@@ -192,6 +192,36 @@ def extra_configs(dev, lib):
 	del gp
 	torch.cuda.empty_cache()
 
+	# GRAM: the Gram fill of the headline fit (N = 65 536, d = 16, SE, fp64) at the C ABI: lower-only (what fit_gp writes: the tiles the
+	# Cholesky reads) and full, against the 8 TB/s spec AND against a plain device fill of the same buffer measured in this process
+	from stpy_amd import _lib as L
+	n, d = 65536, 16
+	xg, _, _ = synth(n, d, 8, dev)
+	ilg = torch.full((d,), 1.0 / math.sqrt(d), dtype=torch.float64, device=dev)
+	Kg = torch.empty((n, n), dtype=torch.float64, device=dev)
+	wsg = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, d)), dtype=torch.uint8, device=dev)
+	gram = {}
+	t_fillg, _ = timed(lambda: Kg.fill_(1.0), reps=3)
+	for lower, tag in ((1, "lower_only"), (0, "full")):
+		tg, _ = timed(lambda: L.check(lib.stpy_gram(L.K_SE, L.F64, L.ptr(xg), n, d, L.ptr(xg), n, d, d, None, L.ptr(ilg), 1.0, 0.0, 0.01, lower, 0,
+														  L.ptr(Kg), n, L.ptr(wsg), wsg.numel(), L.stream_ptr()), "gram"), reps=5)
+		tiles = (n // 128) * (n // 128 + 1) // 2 if lower else (n // 128) ** 2
+		by = tiles * 128 * 128 * 8
+		gram[tag] = {"seconds": round(tg, 5), "bytes": by, "achieved": round(by / tg / 1e12, 2), "frac": round(by / tg / 8e12, 4),
+					 "frac_of_store_ceiling": round((by / tg) / (n * n * 8 / t_fillg), 4)}
+	# parity in the run: 64 sampled rows of the full fill against the oracle's kernel
+	from oracle import gp_oracle as O          # checker only
+	rows = torch.arange(0, n, n // 64, device=dev)
+	refK = O.kernel(xg.cpu().numpy(), xg[rows].cpu().numpy(), [("squared_exponential", {"gamma": math.sqrt(d), "kappa": 1.0}, "-")])
+	refK[np.arange(rows.numel()), rows.cpu().numpy()] += 0.01
+	gerr = float(np.abs(Kg[rows].cpu().numpy() - refK).max())
+	out["GRAM"] = {"workload": "stpy_gram SE N=65536 d=16 fp64 (+ s^2 on the diagonal): the Gram fill of the headline fit", "bound": "hbm", "peak": 8.0, "unit": "TB/s",
+				   "seconds": gram["lower_only"]["seconds"], "achieved": gram["lower_only"]["achieved"], "frac": gram["lower_only"]["frac"], "cases": gram,
+				   "store_ceiling": {"what": "device fill of the same N x N fp64 buffer, same process", "seconds": round(t_fillg, 5), "TB/s": round(n * n * 8 / t_fillg / 1e12, 2)},
+				   "parity": {"max_abs_err_vs_oracle_64_rows": float("%.2e" % gerr), "tolerance": 1e-12}}
+	del Kg, wsg, xg
+	torch.cuda.empty_cache()
+
 	# C3: N = 65 536, d = 16, Matern-5/2, fp32 + log_marginal; parity against the fp64 HIP path on the same inputs
 	n, d, m = 65536, 16, 4096
 	x, y, xt = synth(n, d, m, dev)
@@ -245,8 +275,13 @@ def extra_configs(dev, lib):
 	err = float(np.abs(z[rows].cpu().numpy() - ref).max() / math.sqrt(2.0 / m))
 	bytes_ = n * m * 4 + n * d * 4 + m * d * 4
 	flops = 2.0 * n * d * m
+	# the store-only ceiling of THIS buffer on THIS box: a plain device fill of the same 34.4 GB (the best case of a write stream:
+	# contiguous, no arithmetic, no operand reads), timed the same way
+	t_fill, _ = timed(lambda: z.fill_(1.0), reps=5)
 	out["C5"] = {"workload": "RFF embed N=262144 d=64 m=32768 fp32 (stpy_rff_embed with its workspace, output resident)", "seconds": round(t, 5),
 				 "bound": "hbm", "achieved": round(bytes_ / t / 1e12, 2), "peak": 8.0, "unit": "TB/s", "frac": round(bytes_ / t / 8e12, 4),
+				 "store_ceiling": {"what": "device fill of the same output buffer (n x m fp32), same process", "seconds": round(t_fill, 5),
+								   "TB/s": round(n * m * 4 / t_fill / 1e12, 2), "frac_of_it": round(t_fill / t, 4)},
 				 "arithmetic": "fp32 in / fp32 out; contraction = six bf16 MFMA products of an exact 8+8+8-bit split of both operands, fp32 accumulation "
 							   "(dropped terms < 2^-23 |x||w|); the fp32 MFMA shares the SIMD's ALUs with the trig work, the bf16 matrix pipe does not",
 				 "contraction_tflops_fp32_equivalent": round(flops / t / 1e12, 1),

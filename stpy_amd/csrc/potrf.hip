@@ -12,6 +12,7 @@
 // rows of P are nb*8 bytes apart instead of lda*8, and the GEMM's two operands become the same
 // buffer.  inverse(L_cc) of every diagonal block is kept in `winv` for the triangular solves.
 #include <atomic>
+#include <type_traits>
 #include <map>
 #include <vector>
 #include <mutex>
@@ -188,7 +189,9 @@ extern "C" __attribute__((visibility("default"))) void stpy_debug_set_potf2_buff
 #endif
 constexpr int TRI = IB * (IB + 1) / 2;
 
-__device__ __forceinline__ int tri(int i, int k) { return (i * (i + 1) >> 1) + k; }      // k <= i
+// (24-bit multiply: v_mul_u32_u24 issues at full rate, the 32-bit v_mul_lo_u32 at a quarter -- the index arithmetic of the sub-block
+// products was half of their time; i < 2^12 here)
+__device__ __forceinline__ int tri(int i, int k) { return (int)(__umul24((unsigned)i, (unsigned)(i + 1)) >> 1) + k; }      // k <= i
 
 // broadcast of one lane's value to the whole wave through SGPRs (v_readlane), lane index uniform
 __device__ __forceinline__ double bcast(double v, int src)
@@ -538,6 +541,360 @@ void potf2_trtri_mfma_kernel(T* __restrict__ A, int64_t lda, int nbk, T* W,
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// fp64 diagonal-block kernel, round 4 ("flow" form): the same mathematics as potf2_trtri_mfma_kernel<double> above with the
+// latency chain cut down.  What bounds this kernel is ONE dependent chain -- sub-block kb's factor -> the 16 rows below it ->
+// their diagonal update -> sub-block kb + 1's factor -> ... -- and everything that is not on it should not be in its way:
+//   * the critical wave (7) does that chain itself: it takes the panel rows of sub-block kb + 1, applies them to the diagonal
+//     sub-block (kb + 1, kb + 1) and factors it, with two workgroup barriers per step instead of three (3.25 -> ~2.3 us per step);
+//   * the 16 x 16 factor + inverse is the 4 x 4-blocked MFMA elimination (diag16_f64 below);
+//   * the other seven waves do the remaining panel rows, all other trailing sub-blocks AND the triangular inverse while the
+//     critical wave factors: row i of inverse(L) is formed right after sub-block i is final (W_ij = -WD_i sum_k L_ik W_kj, finished
+//     blocks go to the output array and are read back through the L2 by whichever wave needs them -- the workgroup barriers of the
+//     steps order those accesses); the 6.4 us inverse phase after the factorisation shrinks to the last row's products;
+//   * the critical wave loads sub-block (0, 0) straight from global memory into its registers and starts on it while the other
+//     waves bring the rest of the block into LDS.
+// LDS: the packed lower triangle + the eight inverse diagonal sub-blocks, 83 KiB as before (must fit beside one update workgroup).
+// ------------------------------------------------------------------------------------------
+struct Diag16 {
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	// R = [A | I] (16 x 32) as two C/D fragments (reg r of lane (g, i) = row g + 4r, column i) -> A half = L^T, I half = inverse(L).
+	// The pivot test is a side computation (one compare per pivot, the flag kept in scalar registers): nothing on the dependent
+	// chain waits for it and the pivot is NOT replaced -- a pivot that is not positive turns its reciprocal square root into NaN /
+	// inf and with it the rest of the block (also the rows above it: the masked rank-4 updates multiply 0 by NaN), which is why the
+	// index of the FIRST failing pivot is recorded here and not recovered from the result.  Returns 0 or that 1-based index.
+	static __device__ __forceinline__ int run(v4& RA, v4& RW, int g, int i)
+	{
+		int first_bad = 0;
+		const v4 zero4 = v4{0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int c0 = 4 * k;
+			// D[a][b] sits in reg k of lane (a, 4k + b)
+			const double d00 = bcast(RA[k], 0 * 16 + c0 + 0);
+			const double d10 = bcast(RA[k], 1 * 16 + c0 + 0), d20 = bcast(RA[k], 2 * 16 + c0 + 0), d30 = bcast(RA[k], 3 * 16 + c0 + 0);
+			double d11 = bcast(RA[k], 1 * 16 + c0 + 1);
+			const double d21 = bcast(RA[k], 2 * 16 + c0 + 1), d31 = bcast(RA[k], 3 * 16 + c0 + 1);
+			double d22 = bcast(RA[k], 2 * 16 + c0 + 2);
+			const double d32 = bcast(RA[k], 3 * 16 + c0 + 2);
+			double d33 = bcast(RA[k], 3 * 16 + c0 + 3);
+			// 1/sqrt(d): hardware estimate + two Newton steps; l = d * rl and 1/l = rl
+#define STPY_RSQ(d, rl, jj) first_bad = (!(d > 0.0) && first_bad == 0) ? c0 + jj + 1 : first_bad; \
+			double rl = __builtin_amdgcn_rsq(d); { const double hd_ = 0.5 * d; rl = rl * (1.5 - hd_ * rl * rl); rl = rl * (1.5 - hd_ * rl * rl); }
+			STPY_RSQ(d00, r0, 0)
+			const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+			d11 -= l10 * l10;
+			STPY_RSQ(d11, r1, 1)
+			const double l21 = (d21 - l20 * l10) * r1, l31 = (d31 - l30 * l10) * r1;
+			d22 -= l20 * l20 + l21 * l21;
+			STPY_RSQ(d22, r2, 2)
+			const double l32 = (d32 - l30 * l20 - l31 * l21) * r2;
+			d33 -= l30 * l30 + l31 * l31 + l32 * l32;
+			STPY_RSQ(d33, r3, 3)
+#undef STPY_RSQ
+			// X = inverse(L_kk), lower 4 x 4
+			const double x10 = -r1 * (l10 * r0), x21 = -r2 * (l21 * r1), x32 = -r3 * (l32 * r2);
+			const double x20 = -r2 * (l20 * r0 + l21 * x10), x31 = -r3 * (l31 * r1 + l32 * x21);
+			const double x30 = -r3 * (l30 * r0 + l31 * x10 + l32 * x20);
+			// A operand of X padded to 16 x 4: lane (g, i) holds X[i][g] (i < 4, g <= i), zero elsewhere
+			double xs = 0.0;
+			xs = (i == 0 && g == 0) ? r0 : xs;
+			xs = (i == 1 && g == 0) ? x10 : xs;
+			xs = (i == 1 && g == 1) ? r1 : xs;
+			xs = (i == 2 && g == 0) ? x20 : xs;
+			xs = (i == 2 && g == 1) ? x21 : xs;
+			xs = (i == 2 && g == 2) ? r2 : xs;
+			xs = (i == 3 && g == 0) ? x30 : xs;
+			xs = (i == 3 && g == 1) ? x31 : xs;
+			xs = (i == 3 && g == 2) ? x32 : xs;
+			xs = (i == 3 && g == 3) ? r3 : xs;
+			// normalised row block k = rows 0..3 of X_pad * R_k: reg 0 of the product, lane (g, i) = row g
+			v4 dn0 = MM::mma(xs, RA[k], zero4);
+			v4 dn1 = MM::mma(xs, RW[k], zero4);
+			// both results whole and live together: see potf2_trtri_mfma_kernel (overlapping destination tuples of two MFMAs in flight)
+			asm volatile("" : "+v"(dn0), "+v"(dn1));
+			const double n0 = dn0[0], n1 = dn1[0];
+			if (k < 3) {
+				// M = L[:, 4k..4k+3] below the block: lane (g, i) needs M[i][g] = (L^T)[4k + g][i] = n0 of this very lane
+				const double mop = (i >= c0 + 4) ? n0 : 0.0;
+				RA = MM::mms(mop, n0, RA);
+				RW = MM::mms(mop, n1, RW);
+			}
+			RA[k] = n0;
+			RW[k] = n1;
+		}
+		return first_bad;
+	}
+};
+
+__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, double* W,
+                             double* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
+{
+	typedef double T;
+	typedef Mfma<double> MM;
+	typedef MM::v4 v4;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	T* S = reinterpret_cast<T*>(smem_raw);          // [TRI] packed lower triangle
+	T* WD = S + TRI;                                // [8][16][WLD]
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (uniform: block / task indices derived from it live in SGPRs)
+	const int r16 = lane & 15, g = lane >> 4;
+	constexpr int CW = 7;                           // the critical wave
+
+	// ---- factor + inverse of the diagonal sub-block kb by the critical wave; input from S, or (kb = 0) straight from global memory
+	auto diag_block = [&](int kb, bool from_global) {
+		const int o = kb * SB;
+		v4 RA, RW;
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int row = g + 4 * r;
+			const int hi = row > r16 ? row : r16, lo = row > r16 ? r16 : row;          // the stored (lower) element of the symmetric pair
+			if (from_global) RA[r] = (hi < nbk) ? A[(int64_t)(o + hi) * lda + o + lo] : (hi == lo ? T(1) : T(0));
+			else RA[r] = S[tri(o + hi, o + lo)];
+			RW[r] = (row == r16) ? T(1) : T(0);
+		}
+		const int fb = Diag16::run(RA, RW, g, r16);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int c = g + 4 * r;
+			if (c <= r16) S[tri(o + r16, o + c)] = RA[r];
+			WD[(kb * SB + c) * WLD + r16] = (r16 <= c) ? RW[r] : T(0);
+		}
+		if (fb != 0 && lane == 0) atomicCAS(info, 0, block_row0 + o + fb);
+	};
+	// ---- 16 rows of the panel below sub-block kb: X_bi = A_bi * WD_kb^T (in place in S)
+	auto panel_rows = [&](int kb, int bi) {
+		const int o = kb * SB;
+		v4 acc = v4{0, 0, 0, 0};
+#pragma unroll
+		for (int s4 = 0; s4 < 4; ++s4)
+			acc = MM::mma(S[tri(bi * SB + r16, o + 4 * s4 + g)], WD[(kb * SB + r16) * WLD + 4 * s4 + g], acc);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) S[tri(bi * SB + MM::crow(lane, q), o + r16)] = acc[q];
+	};
+	// ---- one trailing sub-block (bi >= bj > kb): A[bi][bj] -= X_bi X_bj^T  (diagonal sub-blocks: lower part only; the off-diagonal
+	// ---- form carries no lane predicates -- with them hipcc wraps every LDS access in an exec-mask region)
+	auto trail_pair = [&](int kb, int bi, int bj) {
+		const int o = kb * SB;
+		v4 acc;
+		if (bi == bj) {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int rr = MM::crow(lane, q);
+				acc[q] = (r16 <= rr) ? S[tri(bi * SB + rr, bj * SB + r16)] : T(0);
+			}
+#pragma unroll
+			for (int s4 = 0; s4 < 4; ++s4)
+				acc = MM::mms(S[tri(bi * SB + r16, o + 4 * s4 + g)], S[tri(bj * SB + r16, o + 4 * s4 + g)], acc);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int rr = MM::crow(lane, q);
+				if (r16 <= rr) S[tri(bi * SB + rr, bj * SB + r16)] = acc[q];
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; ++q) acc[q] = S[tri(bi * SB + MM::crow(lane, q), bj * SB + r16)];
+#pragma unroll
+			for (int s4 = 0; s4 < 4; ++s4)
+				acc = MM::mms(S[tri(bi * SB + r16, o + 4 * s4 + g)], S[tri(bj * SB + r16, o + 4 * s4 + g)], acc);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) S[tri(bi * SB + MM::crow(lane, q), bj * SB + r16)] = acc[q];
+		}
+	};
+	// ---- row block rb (16 rows) is final once its diagonal sub-block is factored: L to A (lower part) and to the panel copy (zeros
+	// ---- above the diagonal), and of inverse(L) the diagonal sub-block and the zeros to its right (the blocks to its left come from
+	// ---- inverse_block).  `t` of `nt` threads share the 16 x 128 elements.
+	auto writeback_rows = [&](int rb, int t, int nt) {
+		for (int e = t; e < SB * IB; e += nt) {
+			const int i = rb * SB + (e >> 7), j = e & 127;
+			const T v = (j <= i) ? S[tri(i, j)] : T(0);
+			if (i < nbk && j < nbk) {
+				if (j <= i) A[(int64_t)i * lda + j] = v;
+				if (P2) P2[(int64_t)i * ldp2 + j] = v;
+			}
+			const int bj = j >> 4;
+			if (bj > rb) W[i * IB + j] = T(0);
+			else if (bj == rb) W[i * IB + j] = WD[(rb * SB + (i & 15)) * WLD + (j & 15)];
+		}
+	};
+
+	// ---- load: the critical wave takes sub-block (0, 0) from global memory and factors it at once; the other 448 threads bring the
+	// ---- lower triangle (without that sub-block) into LDS, identity on the padding, in batches of loads that are in flight together
+	if (wave == CW) {
+		diag_block(0, true);
+	} else {
+		// the packed triangle is walked as 64 row pairs (p, 127 - p) of 129 elements, so that every thread has the same 19 loads
+		// to issue, all in flight together (one memory round trip)
+		constexpr int NLD = PT_THREADS - 64, NEL = (IB / 2) * (IB + 1), NIT = (NEL + NLD - 1) / NLD;
+		T v[NIT];
+#pragma unroll
+		for (int it = 0; it < NIT; ++it) {
+			const int e = tid + it * NLD, p = e / (IB + 1), q = e - p * (IB + 1);
+			const int i = (q <= p) ? p : IB - 1 - p, j = (q <= p) ? q : q - p - 1;
+			const bool want = e < NEL && i >= SB;                                 // (rows < 16 hold sub-block (0, 0) only)
+			v[it] = (want && i < nbk) ? A[(int64_t)i * lda + j] : ((i == j) ? T(1) : T(0));
+		}
+#pragma unroll
+		for (int it = 0; it < NIT; ++it) {
+			const int e = tid + it * NLD, p = e / (IB + 1), q = e - p * (IB + 1);
+			const int i = (q <= p) ? p : IB - 1 - p, j = (q <= p) ? q : q - p - 1;
+			if (e < NEL && i >= SB) S[tri(i, j)] = v[it];
+		}
+	}
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+	// ---- the steps.  Barrier 1: sub-block kb's factor / inverse and every update of step kb - 1 are visible.  Barrier 2: the panel
+	// ---- rows of step kb are.  Between them all eight waves take panel rows (the critical wave those of sub-block kb + 1); after
+	// ---- barrier 2 the critical wave updates and factors sub-block kb + 1 while the others share the remaining updates
+	// ---- (column kb + 1 first) and row kb of the inverse.
+#ifdef STPY_STAMPS
+	unsigned long long cw_b1 = 0, cw_b2 = 0, cw_de = 0, cw_nb1 = 0, ow_b2 = 0, ow_tr = 0, ow_wb = 0, ow_iv = 0;
+#endif
+	// The barriers of the steps order LDS only (S, WD): nothing read in this kernel was written to global memory by it, so no wave
+	// waits for the L / inverse rows on their way to memory (a microsecond or two until they are acknowledged).  The critical wave
+	// and the others run two separate copies of the step loop with the same barrier sequence (the inverse column a wave keeps in
+	// registers must not be live across the critical wave's factor code, or both spill).
+#define STPY_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+	if (wave == CW) {
+		for (int kb = 0; kb < NSB; ++kb) {
+			STPY_LDS_BARRIER();
+#ifdef STPY_STAMPS
+			if (kb == 3) cw_b1 = __builtin_amdgcn_s_memrealtime();
+			if (kb == 4) cw_nb1 = __builtin_amdgcn_s_memrealtime();
+#endif
+			if (kb + 1 < NSB) panel_rows(kb, kb + 1);
+			STPY_LDS_BARRIER();
+#ifdef STPY_STAMPS
+			if (kb == 3) cw_b2 = __builtin_amdgcn_s_memrealtime();
+#endif
+			if (kb + 1 < NSB) {
+				trail_pair(kb, kb + 1, kb + 1);
+				diag_block(kb + 1, false);
+			}
+#ifdef STPY_STAMPS
+			if (kb == 3) cw_de = __builtin_amdgcn_s_memrealtime();
+#endif
+		}
+	} else {
+		// ---- inverse(L), block column j = this wave's: W_ij = -WD_i * sum_{k=j}^{i-1} L_ik W_kj for i = j+1, j+2, ... -- one block per
+		// ---- step, as soon as row block i of L is final.  The finished blocks of the column stay in this wave's registers (the C/D
+		// ---- fragment of W_kj is the B operand the next product needs) and go to the output array with stores nobody waits for.
+		v4 wcol[NSB - 1];          // wcol[kk - 1] = W_{j+kk, j}
+		auto inverse_step = [&](auto nconst) {
+			constexpr int n = decltype(nconst)::value;          // i = j + n
+			const int j = wave, i = wave + n;
+			v4 t = v4{0, 0, 0, 0};
+#pragma unroll
+			for (int kk = 0; kk < n; ++kk) {
+				const int kx = j + kk;
+#pragma unroll
+				for (int s4 = 0; s4 < 4; ++s4) {
+					const T av = S[tri(i * SB + r16, kx * SB + 4 * s4 + g)];                                       // L_ik[r16][4 s4 + g]
+					const T bv = (kk == 0) ? WD[(j * SB + 4 * s4 + g) * WLD + r16] : wcol[kk == 0 ? 0 : kk - 1][s4];   // W_kj[4 s4 + g][r16]
+					t = MM::mma(av, bv, t);
+				}
+			}
+			v4 w = v4{0, 0, 0, 0};
+#pragma unroll
+			for (int s4 = 0; s4 < 4; ++s4) w = MM::mms(WD[(i * SB + r16) * WLD + 4 * s4 + g], t[s4], w);
+			wcol[n - 1] = w;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
+		};
+		for (int kb = 0; kb < NSB; ++kb) {
+			STPY_LDS_BARRIER();
+			if (kb + 2 + wave < NSB) panel_rows(kb, kb + 2 + wave);
+			STPY_LDS_BARRIER();
+#ifdef STPY_STAMPS
+			if (kb == 3) ow_b2 = __builtin_amdgcn_s_memrealtime();
+#endif
+			// the updates are dealt from wave 6 down: a round that does not go round leaves the extra ones with the waves whose inverse
+			// column is short or has not started
+			int turn = 6;          // (a running counter: the modulo of a pair index costs a dozen scalar instructions per candidate pair)
+			for (int bj = kb + 1; bj < NSB; ++bj)
+				for (int bi2 = (bj == kb + 1 ? bj + 1 : bj); bi2 < NSB; ++bi2) {
+					if (turn == wave) trail_pair(kb, bi2, bj);
+					turn = turn == 0 ? 6 : turn - 1;
+				}
+#ifdef STPY_STAMPS
+			if (kb == 3) ow_tr = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef STPY_STAMPS
+			if (kb == 3) ow_wb = __builtin_amdgcn_s_memrealtime();
+#endif
+			switch (kb - wave) {          // block (kb, wave) of the inverse, if this wave's column has reached row kb
+				case 1: inverse_step(std::integral_constant<int, 1>{}); break;
+				case 2: inverse_step(std::integral_constant<int, 2>{}); break;
+				case 3: inverse_step(std::integral_constant<int, 3>{}); break;
+				case 4: inverse_step(std::integral_constant<int, 4>{}); break;
+				case 5: inverse_step(std::integral_constant<int, 5>{}); break;
+				case 6: inverse_step(std::integral_constant<int, 6>{}); break;
+				case 7: inverse_step(std::integral_constant<int, 7>{}); break;
+				default: break;
+			}
+#ifdef STPY_STAMPS
+			if (kb == 3) ow_iv = __builtin_amdgcn_s_memrealtime();
+#endif
+		}
+	}
+#undef STPY_LDS_BARRIER
+	__syncthreads();
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+	// ---- write L back (and the panel copy with explicit zeros above the diagonal); of inverse(L) the zeros above the diagonal and the
+	// ---- diagonal sub-blocks (the blocks below went out as they were formed).  Measured inside the step loop instead (each row block
+	// ---- as soon as it is final, shared by the seven non-critical waves): ~1 us per row block and wave, more than those waves have
+	// ---- to spare beside the critical wave's 3 us per step -- 39 us against 33 with the write-back here.
+	const bool vec_ok = nbk == IB && ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)(P2 ? P2 : A)) & 15) == 0) && (lda & 1) == 0 && (!P2 || (ldp2 & 1) == 0);
+	if (vec_ok) {
+		// two columns per thread and 16-byte stores: thread t owns the column pair (2 jp, 2 jp + 1) in the rows rs, rs + 8, ... (the strict
+		// upper triangle of A is scratch by contract, so the pair that straddles the diagonal may write its zero)
+		typedef T v2 __attribute__((ext_vector_type(2)));
+		const int jp = tid & 63, rs = tid >> 6, j = 2 * jp, bj = j >> 4;
+		for (int i = rs; i < IB; i += PT_THREADS / 64) {
+			const int bi = i >> 4;
+			v2 v;
+			v.x = (j <= i) ? S[tri(i, j)] : T(0);
+			v.y = (j + 1 <= i) ? S[tri(i, j + 1)] : T(0);
+			if (j <= i) *(v2*)(A + (int64_t)i * lda + j) = v;
+			if (P2) *(v2*)(P2 + (int64_t)i * ldp2 + j) = v;
+			if (bj > bi) *(v2*)(W + i * IB + j) = v2{0, 0};
+			else if (bj == bi) { v2 wv; wv.x = WD[i * WLD + (j & 15)]; wv.y = WD[i * WLD + (j & 15) + 1]; *(v2*)(W + i * IB + j) = wv; }
+		}
+	} else {
+		for (int rb = 0; rb < NSB; ++rb) writeback_rows(rb, tid, PT_THREADS);
+	}
+#ifdef STPY_STAMPS
+	const unsigned long long stamp_t3 = __builtin_amdgcn_s_memrealtime();
+	__syncthreads();
+	if (tid == 0 && stpy_dbg_potf2) {
+		const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+		const unsigned slot = atomicAdd((unsigned*)stpy_dbg_potf2, 1u);
+		if (slot < 1000) { unsigned long long* d = stpy_dbg_potf2 + 2 + 8 * slot; d[0] = stamp_t0; d[1] = stamp_t1; d[2] = stamp_t2; d[3] = stamp_t3; d[4] = t1; stpy_dbg_potf2[1] = slot; }
+	}
+	// step 3 seen from the critical wave: barrier 1 -> barrier 2 (panel rows), barrier 2 -> its sub-block factored, -> next barrier 1 (waiting for the others)
+	__syncthreads();
+	if (tid == CW * 64 && stpy_dbg_potf2) {
+		const unsigned slot = (unsigned)stpy_dbg_potf2[1];
+		if (slot < 1000 && !stpy_dbg_potf2[1000 * 8 + 2]) { unsigned long long* d = stpy_dbg_potf2 + 2 + 8 * slot; d[5] = cw_b2 - cw_b1; d[6] = cw_de - cw_b2; d[7] = cw_nb1 - cw_de; }
+	}
+	// ... or (debug word set) seen from wave 0: its trailing updates, its share of the write-back, its inverse block
+	if (tid == 0 && stpy_dbg_potf2 && stpy_dbg_potf2[1000 * 8 + 2]) {
+		const unsigned slot = (unsigned)stpy_dbg_potf2[1];
+		if (slot < 1000) { unsigned long long* d = stpy_dbg_potf2 + 2 + 8 * slot; d[5] = ow_tr - ow_b2; d[6] = ow_wb - ow_tr; d[7] = ow_iv - ow_wb; }
+	}
+#endif
+}
+
 #if STPY_LAB
 // ------------------------------------------------------------------------------------------
 // "Sliver" form of the same kernel for blocks factored WHILE a trailing update floods the chip (look-ahead panels):
@@ -754,6 +1111,7 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 #endif
 	if (!attr_set[which].load(std::memory_order_acquire)) {
 		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
+		if (e == hipSuccess && sizeof(T) == 8) e = hipFuncSetAttribute((const void*)potf2_trtri_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
 #if STPY_LAB
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_sliver_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliver);
@@ -768,6 +1126,10 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 		hipLaunchKernelGGL((potf2_trtri_sliver_kernel<T>), dim3(1), dim3(PS_THREADS), lds_sliver, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	else
 #endif
+	if constexpr (sizeof(T) == 8) {
+		if (g_potf2_flow) hipLaunchKernelGGL(potf2_trtri_flow_kernel, dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+		else hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	} else
 	hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	(void)beside;
 	return check_launch("potf2_trtri");

@@ -23,10 +23,13 @@ winv = torch.empty(int(lib.stpy_potrf_winv_elems(n)), dtype=torch.float64, devic
 work = torch.empty(int(lib.stpy_potrf_workspace_bytes(L.F64, n, 0)), dtype=torch.uint8, device=dev)
 info = torch.zeros(1, dtype=torch.int32, device=dev)
 ws = torch.empty(int(lib.stpy_gram_workspace_bytes(L.F64, n, n, 8)), dtype=torch.uint8, device=dev)
-buf = torch.zeros(2 + 8 * 1000, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 + 8 * 1000 + 8, dtype=torch.int64, device=dev)
+OTHERS = len(sys.argv) > 2 and sys.argv[2] == "others"
 lib.stpy_debug_set_potf2_buffer(ctypes.c_void_p(buf.data_ptr()))
 for rep in range(3):
 	buf.zero_()
+	if OTHERS:
+		buf[1000 * 8 + 2] = 1
 	L.check(lib.stpy_gram(0, L.F64, L.ptr(x), n, 8, L.ptr(x), n, 8, 8, None, L.ptr(il), 1.0, 0.0, 0.01, 1, 0, L.ptr(K), n, L.ptr(ws), ws.numel(), L.stream_ptr()), "gram")
 	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 	e0.record()
@@ -42,5 +45,11 @@ for rep in range(3):
 	q = cnt // 4
 	print("potrf n=%d: %.2f ms; %d diagonal blocks; in-kernel run time: mean %.1f us, first quarter of the factorisation %.1f, last quarter %.1f, max %.1f"
 		  % (n, e0.elapsed_time(e1), cnt, run.mean(), run[:q].mean(), run[-q:].mean(), run.max()), flush=True)
+	ex = b[2:2 + 8 * cnt].reshape(-1, 8)[:, 5:8].astype(np.float64) / 100.0
+	if ex.any():
+		if OTHERS:
+			print("     step 3 on wave 0: trailing updates %.2f us, write-back share %.2f us, inverse block %.2f us" % tuple(ex.mean(axis=0)), flush=True)
+		else:
+			print("     step 3 on the critical wave: panel rows %.2f us, update + factor of its sub-block %.2f us, waiting for the other waves %.2f us" % tuple(ex.mean(axis=0)), flush=True)
 	for i, name in enumerate(["load block -> LDS", "factor (8 sub-block steps)", "write-back L, diag W", "triangular inverse"]):
 		print("     %-28s first quarter %6.1f us   last quarter %6.1f us" % (name, ph[:q, i].mean(), ph[-q:, i].mean()), flush=True)
