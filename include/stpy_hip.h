@@ -25,7 +25,7 @@
  *         stream must be issued by one thread at a time (they are ordered by the stream, like any HIP work); with them 64 bytes
  *         of device memory (the ticket / counter words of the one-launch vector solve), the library's only allocation;
  *       * the launch profiler's record table (stpy_profile_*), guarded by a mutex, off by default;
- *       * the seven ROUTE switches of stpy_tune (which shipped kernel serves a call where the library normally decides by
+ *       * the eight ROUTE switches of stpy_tune (which shipped kernel serves a call where the library normally decides by
  *         size): process-wide integers read at launch time, never written by the shipped host code -- tests/ use them to
  *         reach every shipped path at small sizes; they must not be changed while another thread is inside the library.
  *         Behaviour a caller may legitimately want per call is a `flags` argument instead (STPY_FLAG_*).  The timing
@@ -285,6 +285,8 @@ int stpy_async_status(void* stream);
  *      from an exact three-way split of both operands (64; 0 = always the fp32 MFMA kernels)
  *   28 fp64 Gram fill: 1 = the dedicated fill kernel for aligned overwriting fills (three small workgroups per CU), 0 = always the
  *      fused epilogue of the MFMA GEMM
+ *   30 fp64 products: plain / lower-only products of at most this many 128 x 128 tiles (and K >= 64) run as 32 x 128 slivers, four
+ *      times the workgroups of the tile kernels (3200; 0 = never) -- the small trailing updates at the end of every factorisation
  * The lab build (libstpy_hip_lab.so) adds the experiment knobs listed in csrc/common.h (STPY_KNOB_LIST). */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */

@@ -418,6 +418,7 @@ void stpy_tune(int key, int value)
 	case 17: g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0; return;
 	case 26: g_gemm_bf3 = value; return;
 	case 28: g_gram_fill = value; return;
+	case 30: g_gemm_sliver_tiles = value; return;
 	default: break;
 	}
 #if STPY_LAB
@@ -440,6 +441,7 @@ int stpy_tune_get(int key)
 	case 17: return g_trsm_strip;
 	case 26: return g_gemm_bf3;
 	case 28: return g_gram_fill;
+	case 30: return g_gemm_sliver_tiles;
 	default: break;
 	}
 #if STPY_LAB

@@ -11,9 +11,9 @@ namespace stpy {
 constexpr int IB = 128;          // inner (diagonal) block of the factorisation / solves
 constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
 // ---- switches ---------------------------------------------------------------------------------------------------------
-// ROUTE switches (stpy_tune keys 5, 8, 9, 16, 17, 26, 28; every build): which of the SHIPPED kernels serves a call where the library
+// ROUTE switches (stpy_tune keys 5, 8, 9, 16, 17, 26, 28, 30; every build): which of the SHIPPED kernels serves a call where the library
 // normally decides by size -- tests/ use them to reach every shipped path at small sizes.  Process-wide, read at launch time.
-extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip, g_gemm_bf3, g_gram_fill;
+extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip, g_gemm_bf3, g_gram_fill, g_gemm_sliver_tiles;
 // EXPERIMENT knobs: compile-time constants in the product library (the measured defaults); variables behind stpy_tune only in
 // the lab build (make EXPERIMENTS=1 -> libstpy_hip_lab.so, used by tools/).  The kernels and code paths that only a non-default
 // value reaches are compiled under #if STPY_LAB, so the product library does not carry them.  Where each default comes from is

@@ -301,6 +301,7 @@ void gram_fill_f64_kernel(GramFillArgs p)
 	}
 }
 
+int g_gemm_sliver_tiles = 3200;         // stpy_tune route key 30: plain / lower-only fp64 products of at most this many 128 x 128 tiles take the 32 x 128 sliver kernel (0 = never)
 int g_gram_fill = 1;          // stpy_tune route key 28: 1 = the dedicated fp64 fill kernel for aligned overwriting fills, 0 = always the GEMM epilogue
 
 // returns 1 when the dedicated kernel took the fill, 0 when the shape / options are not its, < 0 on a launch error
@@ -1354,6 +1355,15 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 	// for a launch that takes 15 us alone).  It is the latency-critical party: top priority for its whole life.
 	__builtin_amdgcn_s_setprio(3);
 	const int row0 = blockIdx.x * SL_TM;
+	// round 4: blockIdx.y = 128-column block of C (and 128-row block of B): the same 32 x 128 sliver serves products of FEW 128 x 128
+	// tiles (small trailing updates, the end of every factorisation): four times the workgroups of the tile kernels, each with a
+	// quarter of a tile's K loop to run -- a 128 x 128 x K tile is 2 * 128^2 * K flop on ONE CU (27 us at K = 256), whatever the
+	// chip has idle.  Lower-only launches skip the column blocks right of the sliver's own 128-row block.
+	const int cb = blockIdx.y;
+	if (p.tri && cb * SL_TN > row0) return;
+	p.B += (int64_t)cb * SL_TN * p.ldb;
+	p.C += cb * SL_TN;
+	if (p.C2) p.C2 += cb * SL_TN;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
 	const int KT = p.k / SL_BK;
@@ -1660,7 +1670,14 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
 	if constexpr (sizeof(T) == 8) {
 		// panel-chain products enqueued beside a trailing update (see gemm_nt_sliver_kernel)
-		if ((gflags & GEMM_BESIDE) && n == SL_TN && (m % SL_TM == 0) && (k % SL_BK == 0) && k >= SL_BK && (mode == 0 || mode == 1) && !lower_only && !bc &&
+		// ... and (round 4, route key 30) plain / lower-only products of few 128 x 128 tiles with K >= 64: see the kernel
+		const int64_t sl_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n;
+		const bool sl_beside = (gflags & GEMM_BESIDE) && n == SL_TN && !lower_only;
+		// (crossover, tools/sliver_vs_tile.py + tools/potrf_sweep.py "30=...": lower-triangular updates up to ~3200 tiles, i.e. 10 000 rows, at every
+		// K = 128 .. 2048 -- 4.8x at 36 tiles, 1.7x at 136, 1.3-1.4x at 528, par at 2080, 0.93x at 4656; rectangles with a long K, the block solve's
+		// products, turn earlier: half the threshold)
+		const bool sl_few = g_gemm_sliver_tiles > 0 && sl_tiles <= (p.tri ? g_gemm_sliver_tiles : g_gemm_sliver_tiles / 2) && (n % SL_TN == 0) && k >= 64 && (!lower_only || p.tri == 1) && lower_only != 2 && n / SL_TN <= 65535;
+		if ((sl_beside || sl_few) && (m % SL_TM == 0) && (k % SL_BK == 0) && k >= SL_BK && (mode == 0 || mode == 1) && !bc &&
 		    p.ksplit == 1 && !g_gemm_exp && (lda % 2 == 0) && (ldb % 2 == 0) && lda < (1 << 24) && ldb < (1 << 24) && ldc < ((int64_t)1 << 28) && ldc2 < ((int64_t)1 << 28) &&
 		    (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {
 			static std::atomic<bool> attr_set{false};
@@ -1670,7 +1687,7 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 				if (e != hipSuccess) { set_error("gemm_nt (sliver): hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
 				attr_set.store(true, std::memory_order_release);
 			}
-			const dim3 gs((unsigned)(m / SL_TM));
+			const dim3 gs((unsigned)(m / SL_TM), (unsigned)(n / SL_TN));
 			if (mode == 1) hipLaunchKernelGGL((gemm_nt_sliver_kernel<true>), gs, block, SL_LDS_BYTES, st, p);
 			else hipLaunchKernelGGL((gemm_nt_sliver_kernel<false>), gs, block, SL_LDS_BYTES, st, p);
 			return check_launch("gemm_nt (sliver)");
