@@ -33,8 +33,11 @@ namespace stpy {
 // kernel alone is 21 of the 35 ms at N = 16 384 (165 us average beside the update, 58 us alone) whatever surrounds it, and keeping
 // the update off eight CUs costs more than that kernel gains.
 // g_potrf_strip = 0 (lab knob, key 18)
-// g_potrf_serial_below = 0:            stpy_tune key 21 (see potrf()): no look-ahead below this many remaining rows.  Off: the fully serial
-                                       // order costs 42.4 ms at N = 16 384 against 35.2 overlapped (the chain ALONE is ~170 us per 128-block at that height)
+// g_potrf_serial_below = 3200:         stpy_tune key 21 (see potrf()): no look-ahead below this many remaining rows.  Round 3 had it off (the fully
+                                       // serial order cost 42.4 ms at N = 16 384 against 35.2 overlapped).  Round 4: with the small trailing updates on the sliver
+                                       // kernel (8-16 us instead of 36-40 per launch) the two event hand-overs of a look-ahead step (16 us each) cost more than the
+                                       // overlap gains once fewer than ~3000 rows are left: potrf 0.50 -> 0.44 / 1.07 -> 0.93 / 2.34 -> 2.18 / 6.31 -> 6.12 /
+                                       // 28.3 -> 28.2 ms at N = 1024 / 2048 / 4096 / 8192 / 16 384 (flat between 2100 and 4200, worse from 6400 on)
 // stpy_tune key 11 (0 = off, the default): blocks factored beside a trailing update take the 64-VGPR / four-wave form below.
 // Measured (tools/potrf_sweep.py, gpurun_out/potrf_sweep3.log): it is placed at once, as intended, but then RUNS 8x slower
 // beside the real update than alone (730-770 us against 94 us in the kernel trace) and loses to the eight-wave kernel that
