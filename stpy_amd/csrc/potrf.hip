@@ -1143,7 +1143,8 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 // the small panel kernels are dispatched ahead of the queued trailing-update workgroups as CU slots free up.
 // Two host threads on two streams get two sets; calls on one stream are enqueued in program order and the events
 // of a set are only ever recorded / awaited by calls on that stream, so re-use across calls needs no further care.
-// g_potrf_diag_first_below = 8192:     stpy_tune key 7
+// g_potrf_diag_first_below = 0:        stpy_tune key 7 (8192 until round 4: with the flow-form diagonal-block kernel and the sliver updates starting the
+//                                       update only after the chain's first kernel no longer pays -- 6.13 -> 5.97 ms at N = 8192, 28.17 -> 28.08 at 16 384)
 // stpy_tune key 10: a look-ahead panel whose trailing update still has at least this many rows runs BESIDE that update and
 // takes the "sliver" GEMM for its panel products (gemm.hip: fits into what two update workgroups leave over on a CU, so it
 // is placed at once) instead of the tile kernels, which wait for an update workgroup to exit, or the 128 KiB one-volley
