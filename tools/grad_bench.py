@@ -10,8 +10,7 @@ x, y, xt = synth(n, d, 128, dev)
 gp = GaussianProcess(gamma=math.sqrt(d), s=0.1, kernel_name="squared_exponential", d=d)
 gp.fit_gp(x, y)
 for rnd in range(2):
-	for alg in (0, 1, 4):
-		lib.stpy_tune(5, alg)
+	for alg in (0,):
 		g = torch.tensor(4.0, dtype=torch.float64, requires_grad=True)
 		torch.cuda.synchronize(); t0 = time.perf_counter()
 		f = gp.log_marginal(gp.kernel_object, {'0': {'gamma': g}}, 1.0)

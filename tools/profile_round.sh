@@ -1,10 +1,10 @@
 #!/bin/bash
-# The round's profiling passes on the GPU box (run from the repo root through gpurun); raw output under gpurun_out/prof_r03/,
+# The round's profiling passes on the GPU box (run from the repo root through gpurun); raw output under gpurun_out/prof_r04/,
 # the summaries that DESIGN.md / bench lines cite are copied into profiles/ afterwards (tools/trace_union.py, tools/pmc_traffic.py).
 # rocprofv3 is given the program itself after `--`; counters are collected in their own passes (no tracing options with --pmc).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/prof_r03
+O=$R/gpurun_out/prof_r04
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/gr_write -o gr -- python3 t
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gr_fetch -o gr -- python3 tools/gram_rff_only.py > $O/gr_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/gr_sq -o gr -- python3 tools/gram_rff_only.py > $O/gr_sq.log 2>&1 || exit 1
 # summaries for profiles/ (copied into the tracked directory by hand after the call)
-TAG=${1:-r03_a}
+TAG=${1:-r04_a}
 S=$O/summaries; mkdir -p $S
 f=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 python3 tools/trace_union.py $f --steps 4 --json $S/${TAG}_bench_n65536_union.json > $S/${TAG}_union.txt 2>&1
@@ -29,4 +29,11 @@ cp $O/kt_line.json $S/${TAG}_bench_n65536_line_under_profiler.json
 python3 tools/pmc_traffic.py $(find $O/pmc_fetch -name '*counter_collection.csv' | head -1) $(find $O/pmc_write -name '*counter_collection.csv' | head -1) $S/${TAG}_bench_n65536_pmc_traffic.json
 cp $(find $O/gr_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_gram_rff_kernel_stats.csv
 python3 tools/gram_rff_pmc.py $O $S/${TAG}_gram_rff_pmc.json > $S/${TAG}_gram_rff_pmc.txt 2>&1 || true
+ls -la $S
+# round 4: the evidence gradient (tools/grad_bench.py) and the fp64 potrf at BASELINE config 2's size under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/grad_kt -o grad -- python3 tools/grad_bench.py > $O/grad_kt.log 2>&1 || true
+cp $(find $O/grad_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_grad_n32768_kernel_stats.csv 2>/dev/null || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2_kt -o c2 -- python3 tools/potrf_only.py 16384 > $O/c2_kt.log 2>&1 || true
+cp $(find $O/c2_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_potrf_n16384_kernel_stats.csv 2>/dev/null || true
+python3 tools/trace_union.py $(find $O/c2_kt -name '*kernel_trace.csv' | head -1) --steps 3 --json $S/${TAG}_potrf_n16384_union.json > /dev/null 2>&1 || true
 ls -la $S
