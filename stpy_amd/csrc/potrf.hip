@@ -1367,7 +1367,14 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		const bool defer = g_potrf_strip == 3 && potrf_panel_can_strip<T>(n, r, nkb, A, lda, winv, ldp);
 		// key 21: below this many remaining rows no look-ahead at all -- the whole trailing update first, then the panel on the same
 		// stream, each alone on the chip (beside the update the chain runs 3-5x slower, and a short update cannot hide it anyway)
-		const bool serial = !reserve && (n - r) <= g_potrf_serial_below;
+		// (lab knob 31, off: serial order also in a band ABOVE the sliver threshold of the trailing update, where the update is the 128 x 128
+		// direct-to-VGPR kernel and the diagonal-block kernel beside it runs 8x slower than alone -- 265 us against 33, kernel trace of
+		// tools/potrf_only.py 16384 -- because every SIMD's fp64 ALUs are held by 64-cycle MFMAs.  Measured: it LOSES, monotonically with the band's
+		// upper edge (N = 16 384: 27.96 ms off, 28.11 / 28.67 / 29.52 / 30.09 with the edge at 11 000 / 12 000 / 14 000 / 16 500 rows; N = 32 768 179.5 ->
+		// 184.0 at 20 000): up there the update and the chain are about balanced (17 ms of update against 19 ms of chain over the first 6000 columns of
+		// N = 16 384) and the serial order gives up the update's own ramp and tail, which the chain otherwise fills.)
+		const int64_t rem_tiles = ((n - r) / IB) * ((n - r) / IB + 1) / 2;
+		const bool serial = !reserve && ((n - r) <= g_potrf_serial_below || (sizeof(T) == 8 && rem_tiles > g_gemm_sliver_tiles && (n - r) <= g_potrf_serial_band));
 		if (serial) {
 			if (r + nkb < n) {
 				const int64_t r2 = r + nkb;
