@@ -280,7 +280,7 @@ int stpy_async_status(void* stream);
  *   9  fp32 RFF route: 1 streaming kernel for large d = 64 shapes (bf16-split form when a workspace is passed) + tile kernel for the
  *      other d = 32 / 64 shapes; 5 the same but always the fp32-MFMA streaming kernel; 2 tile kernel only; 0 GEMM epilogue only
  *   16 vector solves as one dataflow launch for n a multiple of 128 (1; 0: the chain of per-block launches)
- *   17 leaf width of the recursive block solve that runs as one strip launch (1 = 1024 up to 8192 rows, 512 above; 512; 1024; 0 = off)
+ *   17 leaf width of the recursive block solve that runs as one strip launch (1 = the default, 512; 128 / 256 / 512 / 1024; 0 = off)
  *   26 fp32 products: aligned plain / lower-triangular products of at least this many 128 x 128 tiles run on the bf16 matrix cores
  *      from an exact three-way split of both operands (64; 0 = always the fp32 MFMA kernels)
  *   28 fp64 Gram fill: 1 = the dedicated fill kernel for aligned overwriting fills (three small workgroups per CU), 0 = always the

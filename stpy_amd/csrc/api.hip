@@ -415,7 +415,7 @@ void stpy_tune(int key, int value)
 	case 8: g_gemm_k128 = value; return;
 	case 9: if (STPY_LAB || value != 3) g_rff_tile = value; return;          // (3 = the direct-store streaming variant: lab build only)
 	case 16: g_trsv_flow = value; return;
-	case 17: g_trsm_strip = (value == 1 || value == 512 || value == 1024) ? value : 0; return;
+	case 17: g_trsm_strip = (value == 1 || value == 128 || value == 256 || value == 512 || value == 1024) ? value : 0; return;
 	case 26: g_gemm_bf3 = value; return;
 	case 28: g_gram_fill = value; return;
 	case 30: g_gemm_sliver_tiles = value; return;

@@ -153,7 +153,7 @@ void trsm_strip_kernel(const T* __restrict__ Ld, int64_t ldl, const T* __restric
 }
 
 int g_trsm_strip = 1;            // stpy_tune key 17: leaf width of the recursive block solve handled by trsm_strip_kernel (0 = off; 512; 1024;
-                                 // 1 = by row count: 1024 while the m / 16 workgroups fit the chip at once (202 VGPRs: two per CU), 512 above)
+                                 // 1 = the default, 512 since round 4; 128 / 256 / 512 / 1024 force a width)
 
 // Ld: the diagonal block's first element (L + c0 * ldl + c0); W: its first inverse 128-block; X / X2 at the block's first column.
 template <typename T>
@@ -225,7 +225,10 @@ static int trsm_right_looking(int64_t m, int64_t n, const T* L, int64_t ldl, con
 template <typename T>
 static int trsm_recursive(int64_t m, int64_t n, int64_t c0, int64_t w, const T* L, int64_t ldl, const T* winv, T* B, int64_t ldb, hipStream_t st, bool upper_rhs, int64_t leaf, int gflags)
 {
-	const int64_t strip_w = g_trsm_strip == 1 ? (m <= 8192 ? 1024 : 512) : g_trsm_strip;
+	// (round 4: 512 at every row count -- with the products between the leaves on the sliver kernel (gemm.hip, route key 30) the 1024-column
+	// strips of round 2, 140 us each on m / 16 workgroups, no longer pay: tools/trsm_sweep.py 1,128,256,512 17: n = 4096 / 8192 / 16 384, M = 256:
+	// 0.74 -> 0.61, 1.65 -> 1.39, 3.91 -> 3.37 ms; M = 4096: 1.40 -> 1.34, 4.80 -> 4.68, 16.98 -> 16.73; 256 = 512 within 1 %, 128 = the old default)
+	const int64_t strip_w = g_trsm_strip == 1 ? 512 : g_trsm_strip;
 	// (not beside a trailing update: the strip kernel's 120-202 VGPRs do not fit next to two update workgroups; there the
 	// 64-VGPR sliver products of solve_panel stay ahead -- potrf panels with the strip: 35.5 against 34.8 ms at N = 16 384)
 	if (strip_w > 0 && !(gflags & GEMM_BESIDE) && w <= strip_w && w % IB == 0 && !upper_rhs && c0 + w <= n && m < (1 << 30) && trsm_strip_ok(sizeof(T), L, ldl, winv)) {
