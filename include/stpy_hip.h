@@ -238,6 +238,13 @@ int stpy_scaled_points_t(int dtype, const void* x, int64_t n, int64_t ldx, int d
 int stpy_lml_grad_reduce(int dtype, const void* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const void* inv_ls,
                          const void* P, int64_t ldp, const int32_t* pidx, void* acc, void* stream);
 
+/* The same for a full-covariance item (kernels.py:464-549: z = x[:, cols] cov (n x p), then SE / Matern of |z_i - z_j|; the reference differentiates
+ * it by autograd).  With H formed by stpy_lml_weight on the mapped points z (unit lengthscales) and P = H [Z | 1] (n x (p+1)):
+ *   out[a * p + m] -= sum_i x[i*ldx + cols[a]] * (P[i][p] * z[i*ldz + m] - P[i][m]),   a < dg, m < p      (= d evidence / d cov[a][m])
+ * One workgroup, fixed order. */
+int stpy_lml_grad_cov_reduce(int dtype, const void* x, int64_t n, int64_t ldx, int dg, const int32_t* cols,
+                             const void* z, int64_t ldz, int p, const void* P, int64_t ldp, void* out, void* stream);
+
 /*
  * Random Fourier features, replaces RFFEmbedding.embed (embedding.py:225-241):
  *   bias == NULL: out[i*ldo + j] = scale * cos(<W_j, x_i>)  for j <  m/2

@@ -335,6 +335,32 @@ def _item_dk(x, name, p):
 			for m in grp:
 				dk[m] += kg * (xs[:, None, m] - xs[None, :, m]) ** 2 / ag[m] ** 3 / float(len(groups))
 		return k, {"ard_gamma": dk}
+	if name in ("full_covariance_se", "full_covariance_matern"):
+		# kernels.py:464-549: z = x[:, group] cov, then SE (gamma = 1) or Matern on |z_i - z_j| -- torch ops end to end in the reference (mm,
+		# exp / cdist), so autograd yields d/dcov.  k = kappa phi(r):  dk/dcov[a][m] = kappa phi'(r) (z_i - z_j)_m (x_i - x_j)_a / r
+		cov = np.asarray(p["cov"], dtype=np.float64)
+		xs = _cols(x, p.get("group"))
+		z = xs @ cov
+		dz = z[:, None, :] - z[None, :, :]
+		dx = xs[:, None, :] - xs[None, :, :]
+		r = np.sqrt((dz ** 2).sum(-1))
+		kappa = p.get("kappa", 1.0)
+		if name == "full_covariance_se":
+			k = full_covariance_se(x, x, cov, kappa, p.get("group"))
+			fac = -k                                        # phi'(r) / r = -exp(-r^2 / 2)
+		else:
+			nu = p.get("nu", 1.5)
+			k = full_covariance_matern(x, x, cov, nu, kappa, p.get("group"))
+			with np.errstate(divide="ignore", invalid="ignore"):
+				if nu == 0.5:
+					fac = np.where(r > 0, -kappa * np.exp(-r) / r, 0.0)
+				elif nu == 1.5:
+					fac = -3.0 * kappa * np.exp(-SQRT3 * r)
+				elif nu == 2.5:
+					fac = -(5.0 / 3.0) * kappa * (1.0 + SQRT5 * r) * np.exp(-SQRT5 * r)
+				else:
+					raise NotImplementedError("full_covariance_matern gradient: nu in {0.5, 1.5, 2.5}")
+		return k, {"cov": [fac * dz[:, :, m] * dx[:, :, a] for a in range(cov.shape[0]) for m in range(cov.shape[1])]}
 	raise NotImplementedError("no reference gradient for kernel %r (Matern goes through NumPy in the reference, kernels.py:840-859)" % name)
 
 

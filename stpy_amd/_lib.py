@@ -53,6 +53,7 @@ SIGNATURES = {
 	"stpy_trace_dot": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
 	"stpy_scaled_points_t": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
 	"stpy_lml_grad_reduce": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+	"stpy_lml_grad_cov_reduce": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
 	"stpy_rff_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
 	"stpy_rff_embed": (_i32, [_i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _vp, _dbl, _vp, _i64, _i32, _vp, _i64, _vp]),
 	"stpy_profile_enable": (None, [_i32]),

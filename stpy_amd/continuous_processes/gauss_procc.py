@@ -492,7 +492,7 @@ class GaussianProcess(Estimator):
 		overrides in the kwargs protocol of kernels.py:138-157.  With X empty and ``kernel`` the
 		fitted kernel object, the resident factor is reused.
 
-		If a lengthscale tensor in ``X`` ('gamma' / 'ard_gamma') or the noise ``self.s`` requires grad --
+		If a lengthscale tensor in ``X`` ('gamma' / 'ard_gamma'), the map of a full-covariance item ('cov') or the noise ``self.s`` requires grad --
 		the way Estimator.optimize_params_general drives this method (estimator.py:156-190) -- the
 		result carries an autograd node whose backward is the analytic evidence gradient
 		1/2 tr((w K^-1 - alpha alpha^T) dK/dtheta) evaluated on the device (stpy_potri,
@@ -507,7 +507,7 @@ class GaussianProcess(Estimator):
 		"""(key, name, tensor) for every hyper-parameter tensor that asks for a gradient."""
 		out = []
 		for key in sorted(X.keys()) if X else []:
-			for name in ("gamma", "ard_gamma"):
+			for name in ("gamma", "ard_gamma", "cov"):
 				v = X[key].get(name) if isinstance(X[key], dict) else None
 				if torch.is_tensor(v) and v.requires_grad:
 					out.append((key, name, v))
@@ -587,17 +587,23 @@ class GaussianProcess(Estimator):
 			for term in it['terms']:
 				if term['pname'] is None or (str(i), term['pname']) not in acc:
 					continue
-				if term['premap'] is not None:
-					raise NotImplementedError("evidence gradients: full-covariance kernels are not covered")
+				premap = term['premap']
 				group = term['group']
 				identity = (group == list(range(xd.shape[1])))
 				cols = None if identity else _dev_const(group, None, xd.device, int32=True)
 				inv_ls = _dev_const(term['inv_ls'], xd.dtype, xd.device)
+				if premap is not None:
+					# full-covariance item (kernels.py:464-549): the points enter as z = x[:, group] cov with unit lengthscales; the
+					# parameter is the map itself.  d/dcov[a][m] = -1/2 sum_ij H_ij (z_i - z_j)_m (x_i - x_j)_a  (stpy_lml_grad_cov_reduce)
+					kx = kernel._premap(xd, group, premap)                       # (n, p): what the weight / product kernels see as "the points"
+					kcols, kd = None, kx.shape[1]
+				else:
+					kx, kcols, kd = xd, cols, len(group)
 				# H <- (w K^-1 - alpha alpha^T) o kappa F_t: in place over K^-1 when this is the only term, otherwise written
 				# to `work` with K^-1 only read (no N x N copy)
 				H = Kinv if single else work
-				ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, len(group))),), dtype=torch.uint8, device=xd.device)
-				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(xd), n, _lib.ld(xd), len(group), _lib.ptr(cols), _lib.ptr(inv_ls),
+				ws = torch.empty((int(lib.stpy_gram_workspace_bytes(dt, n, n, kd)),), dtype=torch.uint8, device=xd.device)
+				_lib.check(lib.stpy_lml_weight(term['kind'], dt, _lib.ptr(kx), n, _lib.ld(kx), kd, _lib.ptr(kcols), _lib.ptr(inv_ls),
 											   term['kappa'], w, _lib.ptr(alpha), _lib.ptr(Kinv), _lib.ld(Kinv), _lib.ptr(H), _lib.ld(H),
 											   _lib.ptr(ws), ws.numel() * ws.element_size(), st()), "stpy_lml_weight")
 				# ... o M_i
@@ -617,13 +623,19 @@ class GaussianProcess(Estimator):
 					kernel._run_items(fac, xd, xd, tmp)
 					_lib.check(lib.stpy_combine(dt, n, n, _lib.ptr(H), _lib.ld(H), _lib.ptr(tmp), _lib.ld(tmp), _lib.OUT_MUL, 0.0, st()), "stpy_combine")
 				# [Xs | 1]^T (dg + 1, n): scaled coordinates as the NT operand, then P = H [Xs | 1] and the per-coordinate sums
-				dg = len(group)
+				dg = kd
 				XT = torch.empty((dg + 1, n), dtype=xd.dtype, device=xd.device)
-				_lib.check(lib.stpy_scaled_points_t(dt, _lib.ptr(xd), n, _lib.ld(xd), dg, _lib.ptr(cols), _lib.ptr(inv_ls), _lib.ptr(XT), _lib.ld(XT), 1, st()), "stpy_scaled_points_t")
+				_lib.check(lib.stpy_scaled_points_t(dt, _lib.ptr(kx), n, _lib.ld(kx), dg, _lib.ptr(kcols), _lib.ptr(inv_ls), _lib.ptr(XT), _lib.ld(XT), 1, st()), "stpy_scaled_points_t")
 				P = torch.empty((n, dg + 1), dtype=xd.dtype, device=xd.device)
 				_lib.check(lib.stpy_gemm_nt(dt, n, dg + 1, n, _lib.ptr(H), _lib.ld(H), _lib.ptr(XT), _lib.ld(XT), _lib.ptr(P), _lib.ld(P), 0, 0, st()), "stpy_gemm_nt")
-				pidx = _dev_const([int(v) for v in term['pidx']], None, xd.device, int32=True)
 				a_ = acc[(str(i), term['pname'])]
+				if premap is not None:
+					if a_.numel() != len(group) * dg:
+						raise ValueError("evidence gradient: 'cov' has %d entries, the item maps %d columns to %d" % (a_.numel(), len(group), dg))
+					_lib.check(lib.stpy_lml_grad_cov_reduce(dt, _lib.ptr(xd), n, _lib.ld(xd), len(group), _lib.ptr(cols), _lib.ptr(kx), _lib.ld(kx), dg,
+															_lib.ptr(P), _lib.ld(P), _lib.ptr(a_), st()), "stpy_lml_grad_cov_reduce")
+					continue
+				pidx = _dev_const([int(v) for v in term['pidx']], None, xd.device, int32=True)
 				_lib.check(lib.stpy_lml_grad_reduce(dt, _lib.ptr(xd), n, _lib.ld(xd), dg, _lib.ptr(cols), _lib.ptr(inv_ls), _lib.ptr(P), _lib.ld(P),
 													_lib.ptr(pidx), _lib.ptr(a_), st()), "stpy_lml_grad_reduce")
 		del work, work_p

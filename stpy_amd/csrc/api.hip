@@ -377,6 +377,18 @@ int stpy_lml_grad_reduce(int dtype, const void* x, int64_t n, int64_t ldx, int d
 	         lml_grad_reduce<float>((const float*)x, n, ldx, d, cols, (const float*)inv_ls, (const float*)P, ldp, pidx, (float*)acc, st));
 }
 
+int stpy_lml_grad_cov_reduce(int dtype, const void* x, int64_t n, int64_t ldx, int dg, const int32_t* cols,
+                             const void* z, int64_t ldz, int p, const void* P, int64_t ldp, void* out, void* stream)
+{
+	if (n <= 0 || dg <= 0 || p <= 0) return 0;
+	if (!x || !z || !P || !out) { set_error("stpy_lml_grad_cov_reduce: null pointer"); return -2; }
+	if (ldx < 1 || (!cols && ldx < dg) || ldz < p || ldp < p + 1) { set_error("stpy_lml_grad_cov_reduce: bad dimensions"); return -8; }
+	hipStream_t st = (hipStream_t)stream;
+	DISPATCH(dtype,
+	         lml_grad_cov_reduce<double>((const double*)x, n, ldx, dg, cols, (const double*)z, ldz, p, (const double*)P, ldp, (double*)out, st),
+	         lml_grad_cov_reduce<float>((const float*)x, n, ldx, dg, cols, (const float*)z, ldz, p, (const float*)P, ldp, (float*)out, st));
+}
+
 int64_t stpy_rff_workspace_bytes(int dtype, int64_t n, int d, int64_t m)
 {
 	if (n <= 0 || m <= 0 || d <= 0) return 0;

@@ -159,6 +159,9 @@ int trace_dot(int64_t n, const T* A, int64_t lda, const T* u, const T* v, T* out
 template <typename T>
 int scaled_points_t(const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, T* out, int64_t ldo, int ones_row, hipStream_t st);
 template <typename T>
+int lml_grad_cov_reduce(const T* x, int64_t n, int64_t ldx, int dg, const int32_t* cols, const T* z, int64_t ldz, int pdim, const T* P, int64_t ldp,
+                        T* out, hipStream_t st);
+template <typename T>
 int lml_grad_reduce(const T* x, int64_t n, int64_t ldx, int d, const int32_t* cols, const T* inv_ls, const T* P, int64_t ldp,
                     const int32_t* pidx, T* acc, hipStream_t st);
 template <typename T>

@@ -130,7 +130,41 @@ int lml_grad_reduce(const T* x, int64_t n, int64_t ldx, int d, const int32_t* co
 	return check_launch("lml_grad_reduce");
 }
 
+// Full-covariance kernel items (kernels.py:464-549: z = x[:, cols] cov, then a stationary kernel of |z_i - z_j|): with P = H [Z | 1]
+// (n x (p+1), H = (w K^-1 - alpha alpha^T) o kappa F as stpy_lml_weight forms it for the mapped points Z with unit lengthscales),
+//   out[a * p + m] -= sum_i x[i, cols[a]] * (P[i][p] * z[i][m] - P[i][m])       ( = -1/2 sum_ij H_ij (z_i - z_j)_m (x_i - x_j)_a )
+// which is d/dcov[a][m] of the evidence.  One workgroup, the dg x p entries in order, fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(1024)
+void lml_grad_cov_reduce_kernel(const T* __restrict__ x, int64_t ldx, int n, int dg, const int32_t* __restrict__ cols,
+                                const T* __restrict__ z, int64_t ldz, int pdim, const T* __restrict__ P, int64_t ldp, T* __restrict__ out)
+{
+	__shared__ T red[16];
+	for (int a = 0; a < dg; ++a) {
+		const int c = cols ? cols[a] : a;
+		for (int m = 0; m < pdim; ++m) {
+			T s = T(0);
+			for (int i = threadIdx.x; i < n; i += 1024) {
+				const T* Pi = P + (int64_t)i * ldp;
+				s += x[(int64_t)i * ldx + c] * (Pi[pdim] * z[(int64_t)i * ldz + m] - Pi[m]);
+			}
+			s = block_sum_1024(s, red);
+			if (threadIdx.x == 0) out[a * pdim + m] -= s;
+		}
+	}
+}
+
+template <typename T>
+int lml_grad_cov_reduce(const T* x, int64_t n, int64_t ldx, int dg, const int32_t* cols, const T* z, int64_t ldz, int pdim, const T* P, int64_t ldp,
+                        T* out, hipStream_t st)
+{
+	if (n > INT32_MAX) { set_error("lml_grad_cov_reduce: n exceeds int32"); return -2; }
+	hipLaunchKernelGGL((lml_grad_cov_reduce_kernel<T>), dim3(1), dim3(1024), 0, st, x, ldx, (int)n, dg, cols, z, ldz, pdim, P, ldp, out);
+	return check_launch("lml_grad_cov_reduce");
+}
+
 #define INST(T) \
+	template int lml_grad_cov_reduce<T>(const T*, int64_t, int64_t, int, const int32_t*, const T*, int64_t, int, const T*, int64_t, T*, hipStream_t); \
 	template int tril<T>(int64_t, T*, int64_t, hipStream_t); \
 	template int trace_dot<T>(int64_t, const T*, int64_t, const T*, const T*, T*, hipStream_t); \
 	template int scaled_points_t<T>(const T*, int64_t, int64_t, int, const int32_t*, const T*, T*, int64_t, int, hipStream_t); \

@@ -255,7 +255,7 @@ class KernelFunction:
 				cov = arg['cov'] if 'cov' in arg else owner.cov
 				cov = torch.as_tensor(cov).detach().double()
 				kind = _lib.K_SE if name == "full_covariance_se" else self._matern_kind(arg['v'] if 'v' in arg else owner.v)
-				terms = [term(kind, [1.0] * cov.shape[1], premap=cov)]
+				terms = [term(kind, [1.0] * cov.shape[1], premap=cov, pname='cov')]
 			elif name == "polynomial":
 				degree = int(arg['degree'] if 'degree' in arg else owner.power)
 				if degree != (arg['degree'] if 'degree' in arg else owner.power) or degree < 1:

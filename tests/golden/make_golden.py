@@ -536,6 +536,36 @@ def main():
 	save("G15_kf_surface", W=W, x=x, y=y, xtest=xtest, gamma=np.array(0.7), kappa=np.array(kappa15), s=np.array(s15), lam=np.array(lam15),
 		 bound=np.array(1.3), **out)
 
+
+	# ---------------------------------------------------------------- G16: gradients of log_marginal w.r.t. the map of full-covariance kernels
+	# (kernels.py:464-549: z = x[:, group] cov, then SE / Matern on |z_i - z_j| -- torch.mm / exp / cdist, differentiable end to end, so autograd
+	# through the reference's log_marginal yields d/dcov)
+	rng16 = np.random.RandomState(20241116)
+	Ntr, d = 180, 3
+	x = rng16.uniform(-1, 1, size=(Ntr, d))
+	y = np.sin(2 * x[:, :1]) - 0.4 * x[:, 1:2] * x[:, 2:3] + 0.1 * rng16.normal(size=(Ntr, 1))
+	cov16 = np.array([[0.9, 0.2, 0.0], [-0.1, 1.3, 0.3], [0.2, 0.0, 0.7]])
+	cov16g = np.array([[1.1, -0.3], [0.25, 0.8]])
+	out = {}
+
+	def cov_case(tag, make_kernel, cov0):
+		for w in (1.0, 0.5):
+			GP = GaussianProcess(kernel=make_kernel(), s=0.2, d=d)
+			GP.x, GP.y, GP.n = T(x), T(y), Ntr
+			c = torch.tensor(cov0, dtype=torch.float64, requires_grad=True)
+			val = GP.log_marginal(GP.kernel_object, {'0': {'cov': c}}, w)
+			val.backward()
+			sfx = "_w%s" % str(w).replace(".", "")
+			out[tag + sfx + "_value"] = N(val)
+			out[tag + sfx + "_grad"] = N(c.grad)
+		out[tag + "_cov"] = np.asarray(cov0)
+
+	cov_case("se", lambda: KernelFunction(kernel_name="full_covariance_se", cov=T(np.eye(d)), kappa=1.2, d=d), cov16)
+	cov_case("se_group", lambda: KernelFunction(kernel_name="full_covariance_se", cov=T(np.eye(2)), kappa=0.9, d=d, group=[0, 2]), cov16g)
+	cov_case("matern15", lambda: KernelFunction(kernel_name="full_covariance_matern", cov=T(np.eye(d)), nu=1.5, kappa=0.8, d=d), cov16)
+	cov_case("matern25", lambda: KernelFunction(kernel_name="full_covariance_matern", cov=T(np.eye(d)), nu=2.5, kappa=1.1, d=d), cov16)
+	save("G16_lml_grad_cov", x=x, y=y, s=np.array(0.2), **out)
+
 	# ---------------------------------------------------------------- B1: beta() and norm() (gauss_procc.py:179-196)
 	rng3 = np.random.RandomState(20241103)
 	x = rng3.uniform(-1, 1, size=(14, 2)); y = np.sin(x.sum(axis=1, keepdims=True)) + 0.05 * rng3.normal(size=(14, 1))

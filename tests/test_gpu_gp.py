@@ -446,6 +446,33 @@ def test_log_marginal_gradient_pinned_to_reference(S):
 				assert abs(float(sv.grad) - want) / abs(want) < 1e-7, (tag, w)
 
 
+def test_log_marginal_gradient_full_covariance_pinned_to_reference(S):
+	"""The evidence gradient w.r.t. the map of a full-covariance kernel item (kernels.py:464-549; the reference differentiates it by
+	autograd): golden G16 = autograd through the REFERENCE's log_marginal for full_covariance_se (all columns and a column group) and
+	full_covariance_matern (nu = 1.5, 2.5), weights 1 and 0.5.  Value <= 1e-8, gradient <= 1e-7."""
+	g = golden("G16_lml_grad_cov")
+	x, y, s0 = T(g["x"]), T(g["y"]), float(g["s"])
+	d = x.shape[1]
+	KF = S.KernelFunction
+	cases = {
+		"se": lambda: KF(kernel_name="full_covariance_se", cov=torch.eye(d, dtype=torch.float64), kappa=1.2, d=d),
+		"se_group": lambda: KF(kernel_name="full_covariance_se", cov=torch.eye(2, dtype=torch.float64), kappa=0.9, d=d, group=[0, 2]),
+		"matern15": lambda: KF(kernel_name="full_covariance_matern", cov=torch.eye(d, dtype=torch.float64), nu=1.5, kappa=0.8, d=d),
+		"matern25": lambda: KF(kernel_name="full_covariance_matern", cov=torch.eye(d, dtype=torch.float64), nu=2.5, kappa=1.1, d=d),
+	}
+	for tag, mk in cases.items():
+		for w, sfx in ((1.0, "_w10"), (0.5, "_w05")):
+			GP = S.GaussianProcess(kernel=mk(), s=s0, d=d)
+			GP.load_data((x, y))
+			c = torch.from_numpy(g[tag + "_cov"]).clone().requires_grad_(True)
+			f = GP.log_marginal(GP.kernel_object, {'0': {'cov': c}}, w)
+			f.backward()
+			ref = g[tag + sfx + "_value"].ravel()[0]
+			assert abs(float(f.detach()) - ref) / abs(ref) < 1e-8, (tag, w)
+			assert tuple(c.grad.shape) == g[tag + "_cov"].shape
+			assert rel_err(N(c.grad), g[tag + sfx + "_grad"]) < 1e-7, (tag, w, N(c.grad), g[tag + sfx + "_grad"])
+
+
 def _tk(x, kind, ls, kappa, cols=None):
 	"""one kernel matrix in torch CPU autograd (same forms as _torch_lml)"""
 	xs = (x if cols is None else x[:, cols]) / ls

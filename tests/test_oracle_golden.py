@@ -209,6 +209,24 @@ def test_G14_log_marginal_gradient(case):
 		assert abs(gs - ref["grad_s"].ravel()[0]) / abs(ref["grad_s"].ravel()[0]) < 1e-8
 
 
+G16_CASES = [("se", "full_covariance_se", {"kappa": 1.2}), ("se_group", "full_covariance_se", {"kappa": 0.9, "group": [0, 2]}),
+			 ("matern15", "full_covariance_matern", {"kappa": 0.8, "nu": 1.5}), ("matern25", "full_covariance_matern", {"kappa": 1.1, "nu": 2.5})]
+
+
+@pytest.mark.parametrize("tag,name,extra", G16_CASES)
+def test_G16_log_marginal_gradient_full_covariance(tag, name, extra):
+	"""d/dcov of log_marginal for the full-covariance kernels (kernels.py:464-549), from autograd THROUGH THE REFERENCE, against the
+	oracle's analytic trace formula with dk/dcov[a][m] = kappa phi'(r) (z_i - z_j)_m (x_i - x_j)_a / r."""
+	g = golden("G16_lml_grad_cov")
+	cov = g[tag + "_cov"]
+	for w, sfx in ((1.0, "_w10"), (0.5, "_w05")):
+		spec = [(name, dict(extra, cov=cov), "-")]
+		val, grads, _ = O.log_marginal_grad(g["x"], g["y"], spec, float(g["s"]), weight=w)
+		ref = g[tag + sfx + "_value"].ravel()[0]
+		assert abs(val[0, 0] - ref) / abs(ref) < 1e-10
+		assert rel_err(grads[0]["cov"].reshape(cov.shape), g[tag + sfx + "_grad"]) < 1e-8
+
+
 def test_G7_full_prior_execute():
 	g = golden("G7_full_prior")
 	s = float(g["s"])

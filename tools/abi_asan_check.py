@@ -92,6 +92,8 @@ neg(lib.stpy_scaled_points_t(0, P, 4, 4, 2, N, P, P, 3, 1, N), "scaled_points ld
 zero(lib.stpy_scaled_points_t(0, N, 0, 4, 2, N, N, N, 4, 1, N), "scaled_points empty")
 neg(lib.stpy_lml_grad_reduce(0, P, 4, 4, 2, N, P, P, 2, N, P, N), "lml_grad_reduce ldp < d + 1")
 neg(lib.stpy_lml_grad_reduce(0, N, 4, 4, 2, N, P, P, 3, N, P, N), "lml_grad_reduce null x")
+neg(lib.stpy_lml_grad_cov_reduce(0, P, 4, 4, 2, N, N, 2, 2, P, 3, P, N), "lml_grad_cov_reduce null z")
+neg(lib.stpy_lml_grad_cov_reduce(0, P, 4, 4, 2, N, P, 2, 2, P, 2, P, N), "lml_grad_cov_reduce ldp < p + 1")
 # ---- RFF
 assert lib.stpy_rff_workspace_bytes(1, 262144, 64, 32768) > 0 and lib.stpy_rff_workspace_bytes(0, 100, 5, 64) == 0
 neg(lib.stpy_rff_embed(1, N, 16, 4, 4, P, 4, 8, N, N, 1.0, P, 8, 0, N, 0, N), "rff null x")
