@@ -25,7 +25,7 @@
  *         stream must be issued by one thread at a time (they are ordered by the stream, like any HIP work); with them 64 bytes
  *         of device memory (the ticket / counter words of the one-launch vector solve), the library's only allocation;
  *       * the launch profiler's record table (stpy_profile_*), guarded by a mutex, off by default;
- *       * the eight ROUTE switches of stpy_tune (which shipped kernel serves a call where the library normally decides by
+ *       * the nine ROUTE switches of stpy_tune (which shipped kernel serves a call where the library normally decides by
  *         size): process-wide integers read at launch time, never written by the shipped host code -- tests/ use them to
  *         reach every shipped path at small sizes; they must not be changed while another thread is inside the library.
  *         Behaviour a caller may legitimately want per call is a `flags` argument instead (STPY_FLAG_*).  The timing
@@ -113,7 +113,8 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx,
  *       (0 = library default).   info_dev: device int32.
  *       The workspace holds two panel buffers of n x (widest panel) elements.  With nb = 0 the widest panel follows the size:
  *       256 / 512 / 1024 columns up to 2048 / 16 384 / 32 768 rows and 2048 above (since library 0.3: the K = 2048 trailing updates),
- *       i.e. 0.54 GB at n = 32 768, 2.1 GB at n = 65 536 and 4.3 GB at n = 131 072 in fp64 -- on top of the in-place matrix.  ALWAYS
+ *       i.e. 0.54 GB at n = 32 768, 2.1 GB at n = 65 536 and 4.3 GB at n = 131 072 in fp64 -- on top of the in-place matrix.  In fp32 the
+ *       workspace also holds the three bf16 planes of one panel (6 more bytes per panel element: 14 instead of 8; 1.9 GB at n = 65 536).  ALWAYS
  *       size it by the query for the same (dtype, n, nb): a buffer sized by an older build's formula is refused with -20, not overrun.
  */
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb);
@@ -294,6 +295,9 @@ int stpy_async_status(void* stream);
  *      fused epilogue of the MFMA GEMM
  *   30 fp64 products: plain / lower-only products of at most this many 128 x 128 tiles (and K >= 64) run as 32 x 128 slivers, four
  *      times the workgroups of the tile kernels (3200; 0 = never) -- the small trailing updates at the end of every factorisation
+ *   32 fp32 factorisation: 1 = each finished panel is split ONCE into three bf16 planes in the workspace and its trailing updates of
+ *      2048 rows and more run from those planes (gemm_bf3p.hip); 0 = every tile of an update splits its operands on the fly (key 26's
+ *      kernel).  Both give bit-identical factors.
  * The lab build (libstpy_hip_lab.so) adds the experiment knobs listed in csrc/common.h (STPY_KNOB_LIST). */
 void stpy_tune(int key, int value);
 /* current value of a switch (-1: unknown key), so a caller can restore what it changed */

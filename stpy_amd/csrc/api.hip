@@ -139,7 +139,7 @@ int stpy_gram_diag(int kind, int dtype, const void* x, int64_t m, int64_t ldx, i
 int64_t stpy_potrf_workspace_bytes(int dtype, int64_t n, int nb)
 {
 	if (nb <= 0) nb = potrf_auto_nb(n);
-	return 2 * n * (int64_t)nb * (dtype == STPY_F64 ? 8 : 4);     /* two panel workspaces (look-ahead) */
+	return potrf_workspace_bytes(n, nb, dtype == STPY_F64 ? 8 : 4);     /* two panel workspaces (look-ahead); fp32: + the panel's bf16 planes */
 }
 
 int64_t stpy_potrf_winv_elems(int64_t n) { return ((n + IB - 1) / IB) * (int64_t)IB * IB; }
@@ -431,6 +431,7 @@ void stpy_tune(int key, int value)
 	case 26: g_gemm_bf3 = value; return;
 	case 28: g_gram_fill = value; return;
 	case 30: g_gemm_sliver_tiles = value; return;
+	case 32: g_potrf_presplit = value; return;
 	default: break;
 	}
 #if STPY_LAB
@@ -454,6 +455,7 @@ int stpy_tune_get(int key)
 	case 26: return g_gemm_bf3;
 	case 28: return g_gram_fill;
 	case 30: return g_gemm_sliver_tiles;
+	case 32: return g_potrf_presplit;
 	default: break;
 	}
 #if STPY_LAB

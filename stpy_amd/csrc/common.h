@@ -13,7 +13,7 @@ constexpr int POTRF_DEFAULT_NB = 1024, TRSM_DEFAULT_NB = 512;
 // ---- switches ---------------------------------------------------------------------------------------------------------
 // ROUTE switches (stpy_tune keys 5, 8, 9, 16, 17, 26, 28, 30; every build): which of the SHIPPED kernels serves a call where the library
 // normally decides by size -- tests/ use them to reach every shipped path at small sizes.  Process-wide, read at launch time.
-extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip, g_gemm_bf3, g_gram_fill, g_gemm_sliver_tiles;
+extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_strip, g_gemm_bf3, g_gram_fill, g_gemm_sliver_tiles, g_potrf_presplit;
 // EXPERIMENT knobs: compile-time constants in the product library (the measured defaults); variables behind stpy_tune only in
 // the lab build (make EXPERIMENTS=1 -> libstpy_hip_lab.so, used by tools/).  The kernels and code paths that only a non-default
 // value reaches are compiled under #if STPY_LAB, so the product library does not carry them.  Where each default comes from is
@@ -111,6 +111,12 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
             T* C, int64_t ldc, T* C2, int64_t ldc2, int mode, int lower_only, hipStream_t st, const BlockCyclic* bc = nullptr,
             const RffEpilogue<T>* rff = nullptr, const GramEpilogue<T>* gr = nullptr, int ksplit = 1, T* split_work = nullptr, int gflags = 0);
 int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);
+// fp32 trailing updates from a panel split once into three bf16 planes (gemm_bf3p.hip): the split pass, and C -= A B^T with A / B = plane rows arow.. / brow..
+int bf3_split(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsigned short* pl, int64_t ldp, int64_t pstride, int64_t prow0, hipStream_t st);
+int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
+                 float* C, int64_t ldc, int tri, hipStream_t st);
+// bytes of the factorisation's workspace: two panel buffers (look-ahead) and, for fp32, the three bf16 planes of one panel
+inline int64_t potrf_workspace_bytes(int64_t n, int nb, int esize) { return 2 * n * (int64_t)nb * esize + (esize == 4 ? 3 * n * (int64_t)nb * 2 : 0); }
 // dedicated fp64 Gram fill (gemm.hip): 1 = taken, 0 = not this kernel's shape (the caller falls back to the GEMM epilogue), < 0 = error
 int gram_fill_f64(int kind, const double* as, const double* bs, const double* na, const double* nb, int dpad, int64_t n, int64_t q,
                   double kappa, double offset, double diag_add, int lower_only, int combine, double* out, int64_t ldo, hipStream_t st);      // recommended number of K passes for a product with few output tiles

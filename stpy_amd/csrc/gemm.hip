@@ -301,6 +301,7 @@ void gram_fill_f64_kernel(GramFillArgs p)
 	}
 }
 
+int g_potrf_presplit = 1;               // stpy_tune route key 32: the fp32 factorisation splits each panel once into bf16 planes and updates from those (gemm_bf3p.hip; 0 = every tile splits on the fly)
 int g_gemm_sliver_tiles = 3200;         // stpy_tune route key 30: plain / lower-only fp64 products of at most this many 128 x 128 tiles take the 32 x 128 sliver kernel (0 = never)
 int g_gram_fill = 1;          // stpy_tune route key 28: 1 = the dedicated fp64 fill kernel for aligned overwriting fills, 0 = always the GEMM epilogue
 

@@ -1,0 +1,283 @@
+// fp32 trailing updates of the factorisation from a panel that has been split into its three bf16 planes ONCE, in memory.
+//
+// gemm_nt_bf3_kernel (gemm.hip) splits every fp32 operand value on the fly: each workgroup re-splits its A and B rows at every K step
+// (4 VALU operations per value + the byte permutes + 12 LDS stores per thread), and those phases are what keeps its matrix pipe
+// at 55-60 % busy.  In the factorisation both operands of every trailing update are rows of ONE panel that is read by hundreds of tiles:
+// here the panel is split once (bf3_split: a streaming pass, 4 B read + 6 B written per value, ~0.1 ms for a 65 536 x 1024 panel
+// against 10-14 ms of update) into three row-major bf16 planes, and the update kernel below has no vector arithmetic in its K loop at
+// all: the planes go from global memory straight into LDS (global_load_lds_dwordx4, the 16-byte chunk swizzle applied by the choice of
+// SOURCE address, as in the fp64 kernels), and the waves only read fragments and issue MFMAs.
+//
+// Tile: 256 x 128 per workgroup of 8 waves (4 x 2, each 64 x 64), ONE workgroup per CU, two LDS stages of 3 planes x 384 rows x 64 B
+// = 72 KiB each.  Per K step of 32 a wave reads 24 fragments (ds_read_b128) for 96 MFMAs; the CU's LDS moves 192 KiB (1536 cycles at
+// 128 B/clk) under 3072 MFMA cycles per SIMD.  The arithmetic -- the exact truncation split, the six products smallest first, the
+// two-level accumulation in chunks of four K steps, -C in the accumulator and the sign flipped at the store -- is that of
+// gemm_nt_bf3_kernel instruction for instruction per output element, so both routes give bit-identical results
+// (tests/test_gpu_kernels.py::test_f32_factor_presplit_route_is_bit_identical).
+#include "common.h"
+#include <atomic>
+
+namespace stpy {
+
+constexpr int P_TM = 256, P_TN = 128, P_BK = 32;
+constexpr int P_ROWS = P_TM + P_TN;                   // rows of one plane in a stage: A rows 0..255, B rows 256..383
+constexpr int P_PLANE = P_ROWS * 64;                  // 24 KiB
+constexpr int P_STAGE = 3 * P_PLANE;                  // 72 KiB
+constexpr int P_LDS = 2 * P_STAGE;                    // 144 KiB
+constexpr int P_THREADS = 512;
+
+struct Bf3pArgs {
+	const unsigned short* pl;       // plane 0; plane t at pl + t * pstride (elements)
+	int64_t ldp, pstride;
+	int64_t arow, brow;             // first plane row of the A operand / of the B operand
+	float* C;
+	int64_t ldc;
+	int m, n, k;
+	int tri;                        // lower 128 x 128 tiles only (m == n)
+	int nst_m, nst_n, nsuper;       // 1024 x 1024 super-tiles
+	int exp;                        // lab build: timing experiments (results wrong when != 0)
+};
+
+// ---- the split: a thread takes 8 consecutive values of a row
+__global__ __launch_bounds__(256)
+void bf3_split_kernel(const float* __restrict__ X, int64_t ldx, int rows, int cols8, unsigned short* __restrict__ pl, int64_t ldp, int64_t pstride, int64_t prow0)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	typedef unsigned u4v __attribute__((ext_vector_type(4)));
+	// 64 consecutive threads fill one 1 KiB image in order: thread -> (16-row group, K block, row in group, PHYSICAL chunk)
+	const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	const int kbs = cols8 >> 2;                                   // K blocks of X
+	const int64_t im = t >> 6;
+	const int within = (int)(t & 63);
+	const int grp = (int)(im / kbs), kb = (int)(im - (int64_t)grp * kbs);
+	const int r = grp * 16 + (within >> 2);
+	if (r >= rows) return;
+	const int64_t prow = prow0 + r;
+	const int c = (within & 3) ^ (int)((prow >> 1) & 3);          // the logical chunk that lives at this physical position
+	const float* const src = X + (int64_t)r * ldx + kb * 32 + c * 8;
+	const v4f a = *(const v4f*)src, b = *(const v4f*)(src + 4);
+	const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+	unsigned part[3][4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		unsigned h[2][3];
+#pragma unroll
+		for (int e = 0; e < 2; ++e) {
+			const float v = x[2 * q + e];
+			const unsigned u1 = __float_as_uint(v) & 0xffff0000u;
+			const float r1 = v - __uint_as_float(u1);                  // exact: the low 16 significant bits
+			const unsigned u2 = __float_as_uint(r1) & 0xffff0000u;
+			const float r2 = r1 - __uint_as_float(u2);                 // exact: at most 8 significant bits left
+			h[e][0] = u1; h[e][1] = u2; h[e][2] = __float_as_uint(r2);
+		}
+#pragma unroll
+		for (int pt = 0; pt < 3; ++pt) part[pt][q] = __builtin_amdgcn_perm(h[1][pt], h[0][pt], 0x07060302u);          // high halves: [odd value | even value]
+	}
+	const int64_t img = ((prow >> 4) * (ldp >> 5) + kb) * 512 + within * 8;
+#pragma unroll
+	for (int pt = 0; pt < 3; ++pt)
+		*(u4v*)(pl + pt * pstride + img) = u4v{part[pt][0], part[pt][1], part[pt][2], part[pt][3]};
+}
+
+// X: rows x cols fp32 (row i = plane row prow0 + i).  Planes: plane t at pl + t * pstride; a plane is TILE-MAJOR -- for every group of 16 rows and every
+// block of 32 columns one contiguous 1 KiB image in exactly the (swizzled) order the update kernel wants in LDS, groups of a row block side by side
+// (ldp / 32 images per group).  One LDS-DMA wave instruction of the update kernel then reads 1 KiB = eight whole cache lines; with row-major planes it
+// read sixteen half lines, and the operand stream out of the L2s (the kernel's co-limit) moved twice the bytes it used.
+int bf3_split(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsigned short* pl, int64_t ldp, int64_t pstride, int64_t prow0, hipStream_t st)
+{
+	if (rows <= 0 || cols <= 0) return 0;
+	if (cols % 32 != 0 || ldx % 4 != 0 || ldp % 32 != 0 || cols > ldp || pstride % 8 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)pl & 15) || rows > INT32_MAX || prow0 < 0 || prow0 % 16 != 0 || rows % 16 != 0) {
+		set_error("bf3_split: operands must be 16-byte aligned with cols a multiple of 32");
+		return -6;
+	}
+	const int64_t threads = rows * (cols / 8);
+	hipLaunchKernelGGL(bf3_split_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, X, ldx, (int)rows, (int)(cols / 8), pl, ldp, pstride, prow0);
+	return check_launch("bf3_split");
+}
+
+// ---- C -= A B^T  (A = plane rows arow .., B = plane rows brow ..), 256 x 128 tiles
+__global__ __launch_bounds__(P_THREADS, 1)
+void gemm_bf3p_kernel(Bf3pArgs p)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+	typedef unsigned u4v __attribute__((ext_vector_type(4)));
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+	// block -> tile: 32 workgroups (4 row pairs x 8 column tiles = 1024 x 1024 elements) of one super-tile share an XCD (b & 7)
+	const int b = blockIdx.x;
+	const int S = (b & 7) + 8 * (b >> 8);
+	const int w = (b >> 3) & 31;
+	if (S >= p.nsuper) return;
+	int si, sj;
+	if (p.tri) {
+		si = (int)((sqrt(8.0 * (double)S + 1.0) - 1.0) * 0.5);
+		while ((si + 1) * (si + 2) / 2 <= S) ++si;
+		while (si * (si + 1) / 2 > S) --si;
+		sj = S - si * (si + 1) / 2;
+	} else {
+		si = S / p.nst_n;
+		sj = S - si * p.nst_n;
+	}
+	const int row0 = __builtin_amdgcn_readfirstlane((si * 4 + (w >> 3)) * P_TM);
+	const int col0 = __builtin_amdgcn_readfirstlane((sj * 8 + (w & 7)) * P_TN);
+	if (row0 >= p.m || col0 >= p.n) return;
+	if (p.tri && col0 > row0 + 128) return;                       // both 128-row halves lie above the diagonal
+	const int KT = p.k / P_BK;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
+	// a wave computes iff its rows exist and its 128 x 128 tile is on or below the diagonal (the tiles gemm_nt_bf3_kernel computes)
+	const int trow = row0 + (wm >> 1) * 128;
+	const bool active = trow < p.m && !(p.tri && col0 > trow);
+
+	// ---- LDS-DMA: a wave instruction moves 16 plane rows (64 B each) = 1 KiB; wave w moves row groups w, w + 8, w + 16 of every plane.
+	// Lane l lands at row l >> 2, physical chunk l & 3 of its group.
+	// (the planes are tile-major, see bf3_split: a group's image of K block kb is 1 KiB at ((row / 16) * (ldp / 32) + kb) * 1024 bytes, already swizzled)
+	unsigned voff[3];
+#pragma unroll
+	for (int s = 0; s < 3; ++s) {
+		const int g = wave + 8 * s;
+		int64_t prow;                                             // first plane row of the group
+		if (g < 16) { int rr = row0 + g * 16; if (rr > p.m - 16) rr = p.m - 16; prow = p.arow + rr; }
+		else prow = p.brow + col0 + (g - 16) * 16;
+		voff[s] = (unsigned)((prow >> 4) * (p.ldp >> 5) * 1024 + lane * 16);
+	}
+	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+	auto dma_one = [&](const unsigned short* gbase, unsigned vo, unsigned laddr) {
+		unsigned keep;
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep) : "v"(vo), "s"(gbase), "s"(laddr) : "memory");
+	};
+	auto dma_plane = [&](int stage, int k0, int pt) {
+		const unsigned short* const ub = p.pl + pt * p.pstride + (k0 >> 5) * 512;              // uniform: K block k0 / 32
+#pragma unroll
+		for (int s = 0; s < 3; ++s)
+			dma_one(ub, voff[s], lds0 + (unsigned)(stage * P_STAGE + pt * P_PLANE + (wave + 8 * s) * 1024));
+	};
+	auto dma_stage = [&](int stage, int k0) {
+#pragma unroll
+		for (int pt = 0; pt < 3; ++pt) dma_plane(stage, k0, pt);
+	};
+	dma_stage(0, 0);
+
+	// ---- accumulators: -C (the products are accumulated on -C and the sign flipped at the store)
+	v4f acc[4][4];
+	float* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
+	const unsigned ldc32 = (unsigned)p.ldc;
+	if (active) {
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = -crow[tn * 16];
+			}
+	}
+	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): stage 0 has landed (and the C tile)
+	__syncthreads();
+
+	const unsigned frag = (unsigned)r16 * 64u + (unsigned)((kq ^ ((r16 >> 1) & 3)) << 4);
+	const unsigned a_off = (unsigned)(wm * 64) * 64u + frag, b_off = (unsigned)(P_TM + wn * 64) * 64u + frag;
+	constexpr int AP[6] = {0, 0, 1, 0, 1, 2}, BP[6] = {2, 1, 1, 0, 0, 0};
+	constexpr int CHUNK = 4;
+	v4f part[4][4];
+	// One K step: the DMA of stage kt + 1 goes out plane by plane behind the first three MFMA groups (the step's own fragment reads get the
+	// LDS first; 1 % over issuing it all up front) and has the rest of the step to land; one barrier per step.
+	// (tools/bf3p_bench.py, n = 32 768, K = 1024, all-zero operands so that the clock does not move: the step's MFMAs + fragment reads alone
+	// 3.68 ms, its operand DMA alone 3.30 ms, both 4.14-4.19 ms, C tile + barriers alone 0.87 ms -- the operand stream, 72 KiB per CU and step
+	// out of the L2s, is nearly as long as the arithmetic.  With ROW-major planes -- sixteen 64-byte half lines per DMA instruction instead of
+	// eight whole lines -- the DMA alone took 3.73 ms and both 4.44.  Keeping TWO stages in flight -- fragments pulled into registers first, a
+	// second barrier, stage kt + 2 fetched into the buffer just read -- shortened the DMA-only time by 9 % and lengthened the arithmetic by
+	// 7 %: 4.80 ms together; not kept.  Random operands: 5.06 ms against 5.87 for gemm_nt_bf3_kernel -- the clock drops under real data.)
+	auto kstep = [&](auto first_tag, int kt) {
+		constexpr bool FIRST = decltype(first_tag)::value;
+		const bool more = kt + 1 < KT && !(STPY_LAB && (p.exp & 1));
+		if (active && !(STPY_LAB && (p.exp & 2))) {
+			const unsigned char* const sb = smem + (kt & 1) * P_STAGE;
+			bf8 fa[3][4], fb[3][4];
+#pragma unroll
+			for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+				for (int t = 0; t < 4; ++t) {
+					fa[pt][t] = __builtin_bit_cast(bf8, *(const u4v*)(sb + pt * P_PLANE + a_off + t * 16 * 64));
+					fb[pt][t] = __builtin_bit_cast(bf8, *(const u4v*)(sb + pt * P_PLANE + b_off + t * 16 * 64));
+				}
+#pragma unroll
+			for (int g = 0; g < 6; ++g) {
+#pragma unroll
+				for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+					for (int tn = 0; tn < 4; ++tn)
+						part[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[AP[g]][tm], fb[BP[g]][tn], (FIRST && g == 0) ? v4f{0.f, 0.f, 0.f, 0.f} : part[tm][tn], 0, 0, 0);
+				if (more && g < 3) {
+					__builtin_amdgcn_sched_barrier(0);
+					dma_plane((kt + 1) & 1, (kt + 1) * P_BK, g);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			}
+		}
+		else if (more) dma_stage((kt + 1) & 1, (kt + 1) * P_BK);
+		// the next stage has landed (this wave's share) and every wave has read this one
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+	};
+	for (int kc = 0; kc < KT; kc += CHUNK) {
+		kstep(std::true_type{}, kc);
+		for (int j = 1; j < CHUNK && kc + j < KT; ++j) kstep(std::false_type{}, kc + j);
+		if (active) {
+#pragma unroll
+			for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) acc[tm][tn] += part[tm][tn];
+		}
+	}
+	if (active) {
+#pragma unroll
+		for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
+#pragma unroll
+				for (int tn = 0; tn < 4; ++tn) crow[tn * 16] = -acc[tm][tn][i];
+			}
+	}
+}
+
+int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
+                 float* C, int64_t ldc, int tri, hipStream_t st)
+{
+	if (m <= 0 || n <= 0) return 0;
+	if (m % 128 != 0 || n % P_TN != 0 || k % P_BK != 0 || k < P_BK || ldp % 32 != 0 || pstride % 8 != 0 || ((uintptr_t)pl & 15) || (tri && m != n) || arow % 16 != 0 || brow % 16 != 0 ||
+	    m > (1 << 30) || n > (1 << 30) || ldc >= (1 << 24) || ((arow > brow ? arow : brow) + (m > n ? m : n)) * ldp * 2 >= ((int64_t)1 << 32)) {
+		set_error("gemm_nt_bf3p: shape or alignment not supported (m=%lld n=%lld k=%lld)", (long long)m, (long long)n, (long long)k);
+		return -6;
+	}
+	Bf3pArgs p;
+	p.pl = pl; p.ldp = ldp; p.pstride = pstride; p.arow = arow; p.brow = brow; p.C = C; p.ldc = ldc;
+	p.m = (int)m; p.n = (int)n; p.k = (int)k; p.tri = tri ? 1 : 0;
+	p.nst_m = (int)((m + 1023) / 1024); p.nst_n = (int)((n + 1023) / 1024);
+	p.nsuper = p.tri ? p.nst_m * (p.nst_m + 1) / 2 : p.nst_m * p.nst_n;
+	p.exp = g_gemm_exp;
+	const int64_t nblocks = (((int64_t)p.nsuper + 7) / 8) * 256;
+	if (nblocks > INT32_MAX) { set_error("gemm_nt_bf3p: grid too large"); return -2; }
+	static std::atomic<bool> attr_set{false};
+	if (!attr_set.load(std::memory_order_acquire)) {
+		const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+		if (e != hipSuccess) { set_error("gemm_nt_bf3p: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
+		attr_set.store(true, std::memory_order_release);
+	}
+	hipLaunchKernelGGL(gemm_bf3p_kernel, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
+	return check_launch("gemm_nt_bf3p");
+}
+
+}  // namespace stpy
+
+#if STPY_LAB
+// lab build only: the two kernels alone, for tools/bf3p_bench.py
+extern "C" __attribute__((visibility("default"))) int stpy_debug_bf3_split(const float* X, int64_t ldx, int64_t rows, int64_t cols, void* pl, int64_t ldp, int64_t pstride, void* stream)
+{ return stpy::bf3_split(X, ldx, rows, cols, (unsigned short*)pl, ldp, pstride, 0, (hipStream_t)stream); }
+extern "C" __attribute__((visibility("default"))) int stpy_debug_gemm_bf3p(int64_t m, int64_t n, int64_t k, const void* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
+                                                                            float* C, int64_t ldc, int tri, void* stream)
+{ return stpy::gemm_nt_bf3p(m, n, k, (const unsigned short*)pl, ldp, pstride, arow, brow, C, ldc, tri, (hipStream_t)stream); }
+#endif

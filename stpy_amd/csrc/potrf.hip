@@ -1319,6 +1319,10 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 	HIPCHK(hipMemsetAsync(info, 0, sizeof(int32_t), st));
 	const int64_t ldp = nb;                                         // widest panel (the first one)
 	T* Pbuf[2] = {work, work + n * ldp};
+	// fp32 (route key 32): each finished panel is split ONCE into its three bf16 planes (gemm_bf3p.hip: plane t = n x ldp bf16 behind the
+	// two panel buffers) and both of its trailing updates run from those planes -- no per-tile re-split, no vector arithmetic in the K loop
+	unsigned short* const planes = (unsigned short*)(work + 2 * n * ldp);
+	const int64_t pstride = n * ldp;
 	LookAhead* la = nullptr;
 	int rc = lookahead_acquire(st, &la);
 	if (rc) return rc;
@@ -1342,6 +1346,14 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		U = nu;
 		return 0;
 	};
+	// trailing update C[r0:n, r0:r0+cols] -= Pk[r0:n] Pk[r0:r0+cols]^T  (lower: cols = n - r0, lower tiles only), from the planes when `pre`
+	auto update = [&](T* Pk, bool pre, int64_t r0, int64_t cols, int64_t kk, int lower) -> int {
+		if constexpr (sizeof(T) == 4) {
+			if (pre && ((n - r0) / 128) * (cols / 128) >= (lower ? 128 : 64))
+				return gemm_nt_bf3p(n - r0, cols, kk, planes, ldp, pstride, r0, r0, (float*)A + r0 * lda + r0, lda, lower, U);
+		}
+		return gemm_nt<T>(n - r0, cols, kk, Pk + r0 * ldp, ldp, Pk + r0 * ldp, ldp, A + r0 * lda + r0, lda, (T*)nullptr, 0, 1, lower, U);
+	};
 	for (int64_t k = 0; k + wk < n;) {
 		const int64_t r = k + wk;                                   // first row/column of the trailing matrix
 		const int64_t nkb = width(n - r);                           // width of the next panel
@@ -1355,9 +1367,18 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		const bool reserve = want_reserve && la->upd && (n - r) <= g_potrf_reserve_below && (n - r) >= g_potrf_reserve_above && !(gflags & GEMM_BESIDE);
 		rc = switch_to(reserve ? la->upd : st);
 		if (rc) return rc;
+		bool pre = false;
+		if constexpr (sizeof(T) == 4) {
+			pre = g_potrf_presplit && (n - r) % 128 == 0 && (n - r) >= 2048 && wk % 32 == 0 && wk >= 64 && nkb % 128 == 0 && lda < (1 << 24) &&
+			      (((uintptr_t)Pk | (uintptr_t)planes) & 15) == 0 && n * ldp * 2 < ((int64_t)1 << 32);
+			if (pre) {
+				rc = bf3_split((const float*)Pk + r * ldp, ldp, n - r, wk, planes, ldp, pstride, r, U);
+				if (rc) return rc;
+			}
+		}
 		{   // next panel's block column (all rows below r)
 			ProfScope ps(TAG_SYRK, 2.0 * (double)(n - r) * (double)nkb * (double)wk - (double)nkb * (double)nkb * (double)wk, U);
-			rc = gemm_nt<T>(n - r, nkb, wk, Pk + r * ldp, ldp, Pk + r * ldp, ldp, A + r * lda + r, lda, (T*)nullptr, 0, 1, 0, U);
+			rc = update(Pk, pre, r, nkb, wk, 0);
 			if (rc) return rc;
 		}
 		// key 18 = 3: the look-ahead stream factors only the panel's nkb x nkb diagonal block (the latency-bound chain: diagonal-block
@@ -1379,7 +1400,7 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 			if (r + nkb < n) {
 				const int64_t r2 = r + nkb;
 				ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, U);
-				rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, U);
+				rc = update(Pk, pre, r2, n - r2, wk, 1);
 				if (rc) return rc;
 			}
 			rc = factor_panel<T>(n, r, nkb, A, lda, winv, Pbuf[cur ^ 1], ldp, info, U, gflags);
@@ -1405,7 +1426,7 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		if (r + nkb < n) {  // rest of the trailing matrix, lower tiles only
 			const int64_t r2 = r + nkb;
 			ProfScope ps(TAG_SYRK, (double)(n - r2) * (double)(n - r2) * (double)wk, U);      // lower triangle: m^2 k
-			rc = gemm_nt<T>(n - r2, n - r2, wk, Pk + r2 * ldp, ldp, Pk + r2 * ldp, ldp, A + r2 * lda + r2, lda, (T*)nullptr, 0, 1, 1, U);
+			rc = update(Pk, pre, r2, n - r2, wk, 1);
 			if (rc) return rc;
 		}
 		HIPCHK(hipStreamWaitEvent(U, la->panel_done, 0));

@@ -207,6 +207,22 @@ def test_round3_kernels_keep_their_occupancy(tmp_path):
 		assert get(b, r"LDS Size \[bytes/block\]") <= 40 * 1024, n
 
 
+def test_presplit_update_kernel_resources(tmp_path):
+	"""gemm_bf3p_kernel (round 4: fp32 trailing updates from a panel split once into bf16 planes): one 512-thread workgroup per CU = two
+	waves per SIMD, so <= 256 VGPRs with both accumulator sets and all 24 fragments of a K step in registers, no scratch; its 144 KiB of
+	LDS are dynamic (checked at the launch site), so the static size must be 0."""
+	out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", os.path.join(CSRC, "gemm_bf3p.hip"),
+						  "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, check=True).stderr
+	blocks = {b.split()[0]: b for b in re.split(r"remark: Function Name: ", out)[1:]}
+	get = lambda b, key: int(re.search(key + r": (\d+)", b).group(1))
+	k = [b for n, b in blocks.items() if "gemm_bf3p_kernel" in n]
+	assert len(k) == 1
+	assert get(k[0], r"\bVGPRs") + get(k[0], r"\bAGPRs") <= 256 and get(k[0], r"ScratchSize \[bytes/lane\]") == 0 and get(k[0], r"VGPRs Spill") == 0
+	assert get(k[0], r"LDS Size \[bytes/block\]") == 0
+	sp = [b for n, b in blocks.items() if "bf3_split_kernel" in n]
+	assert len(sp) == 1 and get(sp[0], r"ScratchSize \[bytes/lane\]") == 0
+
+
 def test_diag_block_kernel_has_no_overlapping_mfma_destinations(tmp_path):
 	"""potf2_trtri_mfma_kernel<double>: two v_mfma_f64_16x16x4 with a constant C (results of which only element 0 is used) must not
 	be given partially overlapping destination tuples -- hipcc packs them that way when the unused elements are dead, and the

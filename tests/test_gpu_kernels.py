@@ -552,6 +552,35 @@ def test_potrf(L, n, nb):
 		assert np.all(np.triu(W[bi], 1) == 0)
 
 
+def test_f32_factor_presplit_route_is_bit_identical(L):
+	"""Route key 32 (gemm_bf3p.hip): the fp32 factorisation splits each finished panel ONCE into its three bf16 planes and runs both trailing
+	updates from those; with the switch off every tile of the update re-splits its operands on the fly (gemm_nt_bf3_kernel).  The arithmetic
+	per output element is the same sequence of matrix-core instructions, so the two factors must agree bit for bit -- and both against fp64."""
+	lib = L.load()
+	n = 6144                       # panels of 512: trailing matrices of 5632 .. 2048 rows take the planes, the rest the on-the-fly kernel
+	rng = np.random.RandomState(5)
+	x = rng.uniform(-1, 1, size=(n, 6))
+	xx = (x * x).sum(1)
+	K = np.exp(-0.5 * np.maximum(xx[:, None] + xx[None, :] - 2 * x @ x.T, 0) / 0.3 ** 2) + 0.05 * np.eye(n)
+	assert lib.stpy_tune_get(32) == 1
+	outs = []
+	try:
+		for route in (0, 1):
+			lib.stpy_tune(32, route)
+			Ld, winv, info = run_potrf(L, K, 0, torch.float32)
+			assert info == 0
+			outs.append((torch.tril(Ld).clone(), winv.clone()))
+	finally:
+		lib.stpy_tune(32, 1)
+	assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+	Lref = np.linalg.cholesky(K)
+	assert rel_err(outs[1][0].cpu().numpy().astype(np.float64), Lref) < 2e-5
+	# the workspace query covers the planes: two fp32 panel buffers + three bf16 planes of one panel
+	nb = 512
+	assert int(lib.stpy_potrf_workspace_bytes(L.F32, n, nb)) == 2 * n * nb * 4 + 3 * n * nb * 2
+	assert int(lib.stpy_potrf_workspace_bytes(L.F64, n, nb)) == 2 * n * nb * 8
+
+
 def test_potrf_not_positive_definite(L):
 	rng = np.random.RandomState(0)
 	n = 300

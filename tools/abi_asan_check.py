@@ -16,7 +16,7 @@ import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "stpy_amd", "csrc")
-SRCS = ["api", "gemm", "potrf", "solve", "gram", "rff", "reduce"]
+SRCS = ["api", "gemm", "gemm_bf3p", "potrf", "solve", "gram", "rff", "reduce"]
 
 CHILD = r'''
 import ctypes, sys
