@@ -45,6 +45,8 @@ SIGNATURES = {
 	"stpy_predict": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
 	"stpy_logdet_quad": (_i32, [_i32, _i64, _vp, _i64, _vp, _vp, _vp]),
 	"stpy_gemm_nt": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+	"stpy_syrk_workspace_bytes": (_i64, [_i32, _i64, _i64]),
+	"stpy_syrk": (_i32, [_i32, _i64, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
 	"stpy_gemm_nt_splitk_passes": (_i32, [_i64, _i64, _i64]),
 	"stpy_gemm_nt_splitk": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp]),
 	"stpy_gemm_nt_bc": (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

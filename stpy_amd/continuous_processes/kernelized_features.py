@@ -19,7 +19,7 @@ Device mapping -- every contraction is the NT MFMA GEMM because the embedding is
 2 GB by default) and accumulated, so the n x m feature matrix is never materialised (at BASELINE config 5's shape it is 34 GB).
 That requires an embedding that acts ROW BY ROW (each output row depends on its own input row only); every embedding of
 ``stpy_amd.embeddings`` does, and a fit of more than one slab checks it on the first row.
-    V          += Phi_slab^T Phi_slab   stpy_gemm_nt(mode "+="), lower tiles; + s^2 lam on the diagonal: stpy_combine
+    V          += Phi_slab^T Phi_slab   stpy_syrk(mode "+="), lower tiles; + s^2 lam on the diagonal: stpy_combine
     Phi^T y    += Phi_slab^T y_slab     stpy_predict (row sums against y_slab) + stpy_combine(ADD)
     V = L L^T                           stpy_potrf  (the reference takes pinverse(V); V is SPD for s, lam > 0)
     theta                               stpy_trsv forward + backward
@@ -298,8 +298,12 @@ class KernelizedFeatures(GaussianProcess):
 										 "embed(x[0:%d])); the streaming fit needs that -- raise slab_bytes so that one slab holds all rows" % take)
 			V = self._Vacc
 			# V (+)= Phi_slab^T Phi_slab, lower tiles only: mode 0 for the first slab of a fit, 2 (accumulate) afterwards
-			_lib.check(lib.stpy_gemm_nt(dt, m, m, take, _lib.ptr(PhiT), _lib.ld(PhiT), _lib.ptr(PhiT), _lib.ld(PhiT), _lib.ptr(V), _lib.ld(V),
-										0 if first else 2, 1, st()), "stpy_gemm_nt")
+			# (fp32 slabs of 2048 features and more: the slab is split once into bf16 planes in a workspace and every output tile reads those)
+			wb = int(lib.stpy_syrk_workspace_bytes(dt, m, take))
+			work = torch.empty((wb,), dtype=torch.uint8, device=PhiT.device) if wb > 0 else None
+			_lib.check(lib.stpy_syrk(dt, m, take, _lib.ptr(PhiT), _lib.ld(PhiT), _lib.ptr(V), _lib.ld(V), 0 if first else 2,
+									 _lib.ptr(work) if work is not None else None, wb, st()), "stpy_syrk")
+			del work
 			# Phi_slab^T y_slab: row sums of Phi^T against y
 			ys = yd[r0:r0 + take]
 			tgt = self._rhs if first else self._part

@@ -280,6 +280,31 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k, const void* A, int6
 	         gemm_nt<float>(m, n, k, (const float*)A, lda, (const float*)B, ldb, (float*)C, ldc, (float*)nullptr, 0, mode, lower_only, st));
 }
 
+int64_t stpy_syrk_workspace_bytes(int dtype, int64_t n, int64_t k)
+{
+	return (dtype == STPY_F32 && g_gemm_bf3 > 0) ? syrk_planes_workspace_bytes(n, k) : 0;
+}
+
+int stpy_syrk(int dtype, int64_t n, int64_t k, const void* A, int64_t lda, void* C, int64_t ldc, int mode, void* work, int64_t work_bytes, void* stream)
+{
+	if (n <= 0) return 0;
+	if (!A || !C) { set_error("stpy_syrk: null pointer"); return -4; }
+	if (k < 0 || lda < k || ldc < n) { set_error("stpy_syrk: leading dimensions lda=%lld (k=%lld) ldc=%lld (n=%lld)", (long long)lda, (long long)k, (long long)ldc, (long long)n); return -5; }
+	if (mode < 0 || mode > 2) { set_error("stpy_syrk: mode %d (0: C = A A^T, 1: C -= A A^T, 2: C += A A^T)", mode); return -8; }
+	const int imode = mode == 2 ? 5 : mode;
+	hipStream_t st = (hipStream_t)stream;
+	ProfScope ps(TAG_GEMM_API, (double)n * (double)n * (double)k, st);
+	const int64_t need = stpy_syrk_workspace_bytes(dtype, n, k);
+	if (work && need > 0) {
+		WORK_CHECK("stpy_syrk", work_bytes, need);
+		if (lda % 4 == 0 && (((uintptr_t)A | (uintptr_t)work) & 15) == 0 && ldc < (1 << 24))
+			return syrk_planes(n, k, (const float*)A, lda, (float*)C, ldc, imode, work, st);
+	}
+	DISPATCH(dtype,
+	         gemm_nt<double>(n, n, k, (const double*)A, lda, (const double*)A, lda, (double*)C, ldc, (double*)nullptr, 0, imode, 1, st),
+	         gemm_nt<float>(n, n, k, (const float*)A, lda, (const float*)A, lda, (float*)C, ldc, (float*)nullptr, 0, imode, 1, st));
+}
+
 int stpy_gemm_nt_splitk_passes(int64_t m, int64_t n, int64_t k)
 {
 	return gemm_splitk_plan(m, n, k);

@@ -95,10 +95,12 @@ int bf3_split(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsigned 
 	return check_launch("bf3_split");
 }
 
-// ---- C -= A B^T  (A = plane rows arow .., B = plane rows brow ..), 256 x 128 tiles
+// ---- C (op) A B^T  (A = plane rows arow .., B = plane rows brow ..), 256 x 128 tiles.  ACC 0: C = A B^T, 1: C -= A B^T, 2: C += A B^T
+template <int ACC>
 __global__ __launch_bounds__(P_THREADS, 1)
 void gemm_bf3p_kernel(Bf3pArgs p)
 {
+	constexpr bool SUB = ACC == 1, LOADC = ACC != 0;
 	typedef float v4f __attribute__((ext_vector_type(4)));
 	typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 	typedef unsigned u4v __attribute__((ext_vector_type(4)));
@@ -160,7 +162,7 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 	};
 	dma_stage(0, 0);
 
-	// ---- accumulators: -C (the products are accumulated on -C and the sign flipped at the store)
+	// ---- accumulators: zero, or the C tile (negated when subtracting: the products are accumulated on -C and the sign flipped at the store)
 	v4f acc[4][4];
 	float* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
 	const unsigned ldc32 = (unsigned)p.ldc;
@@ -171,7 +173,7 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 			for (int i = 0; i < 4; ++i) {
 				const float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
-				for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = -crow[tn * 16];
+				for (int tn = 0; tn < 4; ++tn) { const float v = LOADC ? crow[tn * 16] : 0.f; acc[tm][tn][i] = SUB ? -v : v; }
 			}
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): stage 0 has landed (and the C tile)
@@ -239,14 +241,15 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 			for (int i = 0; i < 4; ++i) {
 				float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
-				for (int tn = 0; tn < 4; ++tn) crow[tn * 16] = -acc[tm][tn][i];
+				for (int tn = 0; tn < 4; ++tn) crow[tn * 16] = SUB ? -acc[tm][tn][i] : acc[tm][tn][i];
 			}
 	}
 }
 
 int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
-                 float* C, int64_t ldc, int tri, hipStream_t st)
+                 float* C, int64_t ldc, int tri, hipStream_t st, int mode)
 {
+	if (mode != 0 && mode != 1 && mode != 5) { set_error("gemm_nt_bf3p: mode %d", mode); return -11; }
 	if (m <= 0 || n <= 0) return 0;
 	if (m % 128 != 0 || n % P_TN != 0 || k % P_BK != 0 || k < P_BK || ldp % 32 != 0 || pstride % 8 != 0 || ((uintptr_t)pl & 15) || (tri && m != n) || arow % 16 != 0 || brow % 16 != 0 ||
 	    m > (1 << 30) || n > (1 << 30) || ldc >= (1 << 24) || ((arow > brow ? arow : brow) + (m > n ? m : n)) * ldp * 2 >= ((int64_t)1 << 32)) {
@@ -263,12 +266,32 @@ int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int6
 	if (nblocks > INT32_MAX) { set_error("gemm_nt_bf3p: grid too large"); return -2; }
 	static std::atomic<bool> attr_set{false};
 	if (!attr_set.load(std::memory_order_acquire)) {
-		const hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+		hipError_t e = hipFuncSetAttribute((const void*)gemm_bf3p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf3p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
 		if (e != hipSuccess) { set_error("gemm_nt_bf3p: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
 		attr_set.store(true, std::memory_order_release);
 	}
-	hipLaunchKernelGGL(gemm_bf3p_kernel, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
+	if (mode == 1) hipLaunchKernelGGL(gemm_bf3p_kernel<1>, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
+	else if (mode == 5) hipLaunchKernelGGL(gemm_bf3p_kernel<2>, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
+	else hipLaunchKernelGGL(gemm_bf3p_kernel<0>, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
 	return check_launch("gemm_nt_bf3p");
+}
+
+// ---- C (op) A A^T on the lower 128 x 128 tiles, fp32, A split once into the workspace (the feature-space normal equations: every one of the
+// ---- n / 128 row tiles of A is an operand of n / 128 output tiles).  0 bytes = this route does not take the shape.
+int64_t syrk_planes_workspace_bytes(int64_t n, int64_t k)
+{
+	if (n % 128 != 0 || n < 2048 || k % P_BK != 0 || k < 2 * P_BK || n * k * 2 >= ((int64_t)1 << 32)) return 0;
+	return 3 * n * k * 2;
+}
+
+int syrk_planes(int64_t n, int64_t k, const float* A, int64_t lda, float* C, int64_t ldc, int mode, void* work, hipStream_t st)
+{
+	unsigned short* const pl = (unsigned short*)work;
+	int rc = bf3_split(A, lda, n, k, pl, k, n * k, 0, st);
+	if (rc) return rc;
+	return gemm_nt_bf3p(n, n, k, pl, k, n * k, 0, 0, C, ldc, 1, st, mode);
 }
 
 }  // namespace stpy
@@ -279,5 +302,5 @@ extern "C" __attribute__((visibility("default"))) int stpy_debug_bf3_split(const
 { return stpy::bf3_split(X, ldx, rows, cols, (unsigned short*)pl, ldp, pstride, 0, (hipStream_t)stream); }
 extern "C" __attribute__((visibility("default"))) int stpy_debug_gemm_bf3p(int64_t m, int64_t n, int64_t k, const void* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
                                                                             float* C, int64_t ldc, int tri, void* stream)
-{ return stpy::gemm_nt_bf3p(m, n, k, (const unsigned short*)pl, ldp, pstride, arow, brow, C, ldc, tri, (hipStream_t)stream); }
+{ return stpy::gemm_nt_bf3p(m, n, k, (const unsigned short*)pl, ldp, pstride, arow, brow, C, ldc, tri, (hipStream_t)stream, 1); }
 #endif

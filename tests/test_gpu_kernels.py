@@ -33,6 +33,43 @@ def spd(rng, n, d=4, s=0.3):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("n,k,lda_pad", [(2048, 64, 0), (2176, 288, 4), (4096, 1056, 0), (2304, 32 * 37, 12)])
+def test_syrk_from_planes_is_bit_identical_to_gemm_nt(L, n, k, lda_pad):
+	"""stpy_syrk with its workspace (fp32: A split once into tile-major bf16 planes, gemm_bf3p.hip) against stpy_gemm_nt(A, A, lower_only)
+	(every tile splits on the fly): all three modes, bit for bit on the lower tiles; and against an fp64 product."""
+	lib = L.load()
+	torch.manual_seed(n + k)
+	lda = k + lda_pad
+	Abuf = torch.randn(n, lda, dtype=torch.float32, device="cuda:0")
+	A = Abuf[:, :k]
+	wb = int(lib.stpy_syrk_workspace_bytes(L.F32, n, k))
+	assert wb == 3 * n * k * 2
+	work = torch.empty(wb, dtype=torch.uint8, device="cuda:0")
+	C0 = torch.randn(n, n, dtype=torch.float32, device="cuda:0")
+	low = torch.ones(n // 128, n // 128, device="cuda:0").tril().bool().repeat_interleave(128, 0).repeat_interleave(128, 1)      # the lower 128 x 128 tiles
+	ref64 = A.double() @ A.double().T
+	for mode in (0, 1, 2):
+		Ca, Cb = C0.clone(), C0.clone()
+		L.check(lib.stpy_gemm_nt(L.F32, n, n, k, L.ptr(A), lda, L.ptr(A), lda, L.ptr(Ca), n, mode, 1, L.stream_ptr()), "gemm")
+		L.check(lib.stpy_syrk(L.F32, n, k, L.ptr(A), lda, L.ptr(Cb), n, mode, L.ptr(work), wb, L.stream_ptr()), "syrk")
+		torch.cuda.synchronize()
+		assert torch.equal(Ca[low], Cb[low]), mode
+		assert torch.equal(Cb[~low], C0[~low])                    # tiles above the diagonal untouched
+		want = {0: ref64, 1: C0.double() - ref64, 2: C0.double() + ref64}[mode]
+		assert float((Cb.double() - want)[low].abs().max()) < 2e-5 * float(want.abs().max())
+	# without a workspace, in fp64, or for a shape the route does not take: the plain product
+	Cc = C0.clone()
+	L.check(lib.stpy_syrk(L.F32, n, k, L.ptr(A), lda, L.ptr(Cc), n, 1, None, 0, L.stream_ptr()), "syrk")
+	Cd = C0.clone()
+	L.check(lib.stpy_gemm_nt(L.F32, n, n, k, L.ptr(A), lda, L.ptr(A), lda, L.ptr(Cd), n, 1, 1, L.stream_ptr()), "gemm")
+	assert torch.equal(Cc[low], Cd[low])
+	assert int(lib.stpy_syrk_workspace_bytes(L.F64, n, k)) == 0 and int(lib.stpy_syrk_workspace_bytes(L.F32, 1920, k)) == 0
+	A64 = torch.randn(300, 70, dtype=torch.float64, device="cuda:0")
+	C64 = torch.zeros(300, 300, dtype=torch.float64, device="cuda:0")
+	L.check(lib.stpy_syrk(L.F64, 300, 70, L.ptr(A64), 70, L.ptr(C64), 300, 0, None, 0, L.stream_ptr()), "syrk")
+	assert rel_err(np.tril(C64.cpu().numpy()), np.tril((A64 @ A64.T).cpu().numpy())) < 1e-14
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 384, 128), (300, 200, 70), (1, 130, 5), (513, 129, 257), (1024, 1024, 512)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_nt(L, m, n, k, mode):

@@ -78,6 +78,12 @@ neg(lib.stpy_gemm_nt(0, 4, 4, 4, N, 4, P, 4, P, 4, 0, 0, N), "gemm null A")
 neg(lib.stpy_gemm_nt(0, 4, 4, 4, P, 2, P, 4, P, 4, 0, 0, N), "gemm lda < k")
 neg(lib.stpy_gemm_nt(0, 256, 256, 16, P, 16, P, 16, P, 1 << 25, 0, 0, N), "gemm ldc >= 2^25")
 neg(lib.stpy_gemm_nt(9, 4, 4, 4, P, 4, P, 4, P, 4, 0, 0, N), "gemm unknown dtype")
+neg(lib.stpy_syrk(1, 4096, 64, N, 64, P, 4096, 0, N, 0, N), "syrk null A")
+neg(lib.stpy_syrk(1, 4096, 64, P, 32, P, 4096, 0, N, 0, N), "syrk lda < k")
+neg(lib.stpy_syrk(1, 4096, 64, P, 64, P, 4096, 3, N, 0, N), "syrk unknown mode")
+neg(lib.stpy_syrk(1, 4096, 64, P, 64, P, 4096, 0, P, 16, N), "syrk undersized workspace")
+zero(lib.stpy_syrk(1, 0, 64, N, 64, N, 1, 0, N, 0, N), "syrk empty")
+assert lib.stpy_syrk_workspace_bytes(1, 4096, 64) == 3 * 4096 * 64 * 2 and lib.stpy_syrk_workspace_bytes(0, 4096, 64) == 0 and lib.stpy_syrk_workspace_bytes(1, 1000, 64) == 0
 assert lib.stpy_gemm_nt_splitk_passes(128, 128, 65536) >= 1
 neg(lib.stpy_gemm_nt_splitk(0, 128, 128, 4096, P, 4096, P, 4096, P, 128, 0, 4, P, 8, N), "splitk workspace too small")
 neg(lib.stpy_gemm_nt_bc(0, 256, 256, 128, P, 128, P, 128, P, 256, 1, 100, 1, 1, 0, 0, 0, 0, N), "gemm_bc block not a multiple of 128")
@@ -101,7 +107,7 @@ neg(lib.stpy_rff_embed(1, P, 16, 2, 4, P, 4, 8, N, N, 1.0, P, 8, 0, N, 0, N), "r
 neg(lib.stpy_rff_embed(1, P, 262144, 64, 64, P, 64, 32768, N, N, 1.0, P, 32768, 0, P, 16, N), "rff undersized workspace")
 zero(lib.stpy_rff_embed(1, N, 0, 4, 4, N, 4, 8, N, N, 1.0, N, 8, 0, N, 0, N), "rff empty")
 # ---- switches and profiler (no device needed)
-for key in (5, 8, 9, 16, 17, 26, 28, 30):
+for key in (5, 8, 9, 16, 17, 26, 28, 30, 32):
     v = lib.stpy_tune_get(key); assert v >= 0; lib.stpy_tune(key, v)
 assert lib.stpy_tune_get(12345) == -1
 lib.stpy_tune(12345, 1)
