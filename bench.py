@@ -37,7 +37,7 @@ PEAK_FP64_MFMA_TFLOPS = 78.6       # MI355X fp64 matrix, vendor dense figure (SU
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X fp32 matrix (MI355X_MICROARCH.md: 155 measured)
 PEAK_BF16X3_TFLOPS = 2500.0 / 6.0  # fp32-equivalent ceiling of the exact three-way bf16 split (six bf16 MFMA products per fp32 product; dense bf16 peak 2.5 PFLOP/s)
 BF16X3_NOTE = ("fp32 in / fp32 out; the large aligned products run on the bf16 matrix cores from an EXACT three-way split of both operands (six products, "
-			   "two-level fp32 accumulation; gemm_nt_bf3_kernel) -- `peak` / `frac` are those of the pipe that bounds the kernel: the dense bf16 MFMA "
+			   "two-level fp32 accumulation; gemm_bf3p_kernel from operands split once into bf16 planes where an operand is reused by many tiles -- the factorisation's panels, the feature slabs -- and gemm_nt_bf3_kernel, which splits on the fly, elsewhere; the two are bit-identical) -- `peak` / `frac` are those of the pipe that bounds the kernel: the dense bf16 MFMA "
 			   "peak / 6 products = 416.7 TFLOP/s fp32-equivalent; `ratio_to_fp32_mfma_peak` relates the same rate to the 157.3 TFLOP/s fp32-MFMA "
 			   "pipe the config was priced against in rounds 1-2 (a comparison, not a roofline fraction)")
 

@@ -631,9 +631,13 @@ struct Diag16 {
 	}
 };
 
+// TS: the type of the matrix in memory.  The arithmetic is fp64 for both -- the kernel is a latency chain, not a throughput kernel, and an fp32
+// block factored in fp64 is rounded once, at the store (round 4: the fp32 factorisation's diagonal blocks, 90 us in the fp32 form of the
+// kernel above, take this kernel too).
+template <typename TS>
 __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, double* W,
-                             double* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
+void potf2_trtri_flow_kernel(TS* __restrict__ A, int64_t lda, int nbk, TS* W,
+                             TS* __restrict__ P2, int64_t ldp2, int32_t* info, int block_row0)
 {
 	typedef double T;
 	typedef Mfma<double> MM;
@@ -657,7 +661,7 @@ void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, doubl
 		for (int r = 0; r < 4; ++r) {
 			const int row = g + 4 * r;
 			const int hi = row > r16 ? row : r16, lo = row > r16 ? r16 : row;          // the stored (lower) element of the symmetric pair
-			if (from_global) RA[r] = (hi < nbk) ? A[(int64_t)(o + hi) * lda + o + lo] : (hi == lo ? T(1) : T(0));
+			if (from_global) RA[r] = (hi < nbk) ? (T)A[(int64_t)(o + hi) * lda + o + lo] : (hi == lo ? T(1) : T(0));
 			else RA[r] = S[tri(o + hi, o + lo)];
 			RW[r] = (row == r16) ? T(1) : T(0);
 		}
@@ -717,12 +721,12 @@ void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, doubl
 			const int i = rb * SB + (e >> 7), j = e & 127;
 			const T v = (j <= i) ? S[tri(i, j)] : T(0);
 			if (i < nbk && j < nbk) {
-				if (j <= i) A[(int64_t)i * lda + j] = v;
-				if (P2) P2[(int64_t)i * ldp2 + j] = v;
+				if (j <= i) A[(int64_t)i * lda + j] = (TS)v;
+				if (P2) P2[(int64_t)i * ldp2 + j] = (TS)v;
 			}
 			const int bj = j >> 4;
-			if (bj > rb) W[i * IB + j] = T(0);
-			else if (bj == rb) W[i * IB + j] = WD[(rb * SB + (i & 15)) * WLD + (j & 15)];
+			if (bj > rb) W[i * IB + j] = TS(0);
+			else if (bj == rb) W[i * IB + j] = (TS)WD[(rb * SB + (i & 15)) * WLD + (j & 15)];
 		}
 	};
 
@@ -740,7 +744,7 @@ void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, doubl
 			const int e = tid + it * NLD, p = e / (IB + 1), q = e - p * (IB + 1);
 			const int i = (q <= p) ? p : IB - 1 - p, j = (q <= p) ? q : q - p - 1;
 			const bool want = e < NEL && i >= SB;                                 // (rows < 16 hold sub-block (0, 0) only)
-			v[it] = (want && i < nbk) ? A[(int64_t)i * lda + j] : ((i == j) ? T(1) : T(0));
+			v[it] = (want && i < nbk) ? (T)A[(int64_t)i * lda + j] : ((i == j) ? T(1) : T(0));
 		}
 #pragma unroll
 		for (int it = 0; it < NIT; ++it) {
@@ -809,7 +813,7 @@ void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, doubl
 			for (int s4 = 0; s4 < 4; ++s4) w = MM::mms(WD[(i * SB + r16) * WLD + 4 * s4 + g], t[s4], w);
 			wcol[n - 1] = w;
 #pragma unroll
-			for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = w[q];
+			for (int q = 0; q < 4; ++q) W[(i * SB + MM::crow(lane, q)) * IB + j * SB + r16] = (TS)w[q];
 		};
 		for (int kb = 0; kb < NSB; ++kb) {
 			STPY_LDS_BARRIER();
@@ -857,21 +861,21 @@ void potf2_trtri_flow_kernel(double* __restrict__ A, int64_t lda, int nbk, doubl
 	// ---- diagonal sub-blocks (the blocks below went out as they were formed).  Measured inside the step loop instead (each row block
 	// ---- as soon as it is final, shared by the seven non-critical waves): ~1 us per row block and wave, more than those waves have
 	// ---- to spare beside the critical wave's 3 us per step -- 39 us against 33 with the write-back here.
-	const bool vec_ok = nbk == IB && ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)(P2 ? P2 : A)) & 15) == 0) && (lda & 1) == 0 && (!P2 || (ldp2 & 1) == 0);
+	const bool vec_ok = nbk == IB && ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)(P2 ? P2 : A)) & (2 * sizeof(TS) - 1)) == 0) && (lda & 1) == 0 && (!P2 || (ldp2 & 1) == 0);
 	if (vec_ok) {
-		// two columns per thread and 16-byte stores: thread t owns the column pair (2 jp, 2 jp + 1) in the rows rs, rs + 8, ... (the strict
+		// two columns per thread and 16-byte (fp32 matrix: 8-byte) stores: thread t owns the column pair (2 jp, 2 jp + 1) in the rows rs, rs + 8, ... (the strict
 		// upper triangle of A is scratch by contract, so the pair that straddles the diagonal may write its zero)
-		typedef T v2 __attribute__((ext_vector_type(2)));
+		typedef TS v2 __attribute__((ext_vector_type(2)));
 		const int jp = tid & 63, rs = tid >> 6, j = 2 * jp, bj = j >> 4;
 		for (int i = rs; i < IB; i += PT_THREADS / 64) {
 			const int bi = i >> 4;
 			v2 v;
-			v.x = (j <= i) ? S[tri(i, j)] : T(0);
-			v.y = (j + 1 <= i) ? S[tri(i, j + 1)] : T(0);
+			v.x = (TS)((j <= i) ? S[tri(i, j)] : T(0));
+			v.y = (TS)((j + 1 <= i) ? S[tri(i, j + 1)] : T(0));
 			if (j <= i) *(v2*)(A + (int64_t)i * lda + j) = v;
 			if (P2) *(v2*)(P2 + (int64_t)i * ldp2 + j) = v;
 			if (bj > bi) *(v2*)(W + i * IB + j) = v2{0, 0};
-			else if (bj == bi) { v2 wv; wv.x = WD[i * WLD + (j & 15)]; wv.y = WD[i * WLD + (j & 15) + 1]; *(v2*)(W + i * IB + j) = wv; }
+			else if (bj == bi) { v2 wv; wv.x = (TS)WD[i * WLD + (j & 15)]; wv.y = (TS)WD[i * WLD + (j & 15) + 1]; *(v2*)(W + i * IB + j) = wv; }
 		}
 	} else {
 		for (int rb = 0; rb < NSB; ++rb) writeback_rows(rb, tid, PT_THREADS);
@@ -1106,6 +1110,7 @@ template <typename T>
 int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* info, int block_row0, hipStream_t st, bool beside)
 {
 	const size_t lds_new = (size_t)(TRI + NSB * SB * WLD + (sizeof(T) == 4 ? 8 * SB * WLD : 0)) * sizeof(T);
+	const size_t lds_flow = (size_t)(TRI + NSB * SB * WLD) * sizeof(double);          // (the flow kernel computes in fp64 whatever the matrix type)
 	static std::atomic<bool> attr_set[2];          // (idempotent: two threads racing here both set the same attribute values)
 	const int which = sizeof(T) == 8 ? 0 : 1;
 #if STPY_LAB
@@ -1114,7 +1119,7 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 #endif
 	if (!attr_set[which].load(std::memory_order_acquire)) {
 		hipError_t e = hipFuncSetAttribute((const void*)potf2_trtri_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
-		if (e == hipSuccess && sizeof(T) == 8) e = hipFuncSetAttribute((const void*)potf2_trtri_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_new);
+		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_flow_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_flow);
 #if STPY_LAB
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old);
 		if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potf2_trtri_sliver_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliver);
@@ -1129,11 +1134,8 @@ int potf2_trtri(T* A, int64_t lda, int nbk, T* W, T* P2, int64_t ldp2, int32_t* 
 		hipLaunchKernelGGL((potf2_trtri_sliver_kernel<T>), dim3(1), dim3(PS_THREADS), lds_sliver, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	else
 #endif
-	if constexpr (sizeof(T) == 8) {
-		if (g_potf2_flow) hipLaunchKernelGGL(potf2_trtri_flow_kernel, dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
-		else hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
-	} else
-	hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	if (g_potf2_flow && (sizeof(T) == 8 || g_potf2_flow != 2)) hipLaunchKernelGGL((potf2_trtri_flow_kernel<T>), dim3(1), dim3(PT_THREADS), lds_flow, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
+	else hipLaunchKernelGGL((potf2_trtri_mfma_kernel<T>), dim3(1), dim3(PT_THREADS), lds_new, st, A, lda, nbk, W, P2, ldp2, info, block_row0);
 	(void)beside;
 	return check_launch("potf2_trtri");
 }

@@ -233,7 +233,7 @@ def test_diag_block_kernel_has_no_overlapping_mfma_destinations(tmp_path):
 	subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-S", "--cuda-device-only",
 					os.path.join(CSRC, "potrf.hip"), "-o", str(asm)], check=True, capture_output=True)
 	lines = asm.read_text().splitlines()
-	for sym in ("_ZN4stpy23potf2_trtri_mfma_kernelIdEE", "_ZN4stpy23potf2_trtri_flow_kernelE"):
+	for sym in ("_ZN4stpy23potf2_trtri_mfma_kernelIdEE", "_ZN4stpy23potf2_trtri_flow_kernelIdEE", "_ZN4stpy23potf2_trtri_flow_kernelIfEE"):          # (the flow kernel computes in fp64 for both matrix types)
 		_check_mfma_pairs(lines, sym)
 
 
