@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/gr_write -o gr -- python3 t
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gr_fetch -o gr -- python3 tools/gram_rff_only.py > $O/gr_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/gr_sq -o gr -- python3 tools/gram_rff_only.py > $O/gr_sq.log 2>&1 || exit 1
 # summaries for profiles/ (copied into the tracked directory by hand after the call)
-TAG=${1:-r04_a}
+TAG=${1:-r04_b}
 S=$O/summaries; mkdir -p $S
 f=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 python3 tools/trace_union.py $f --steps 4 --json $S/${TAG}_bench_n65536_union.json > $S/${TAG}_union.txt 2>&1
@@ -36,4 +36,11 @@ cp $(find $O/grad_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_grad_n32768_
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2_kt -o c2 -- python3 tools/potrf_only.py 16384 > $O/c2_kt.log 2>&1 || true
 cp $(find $O/c2_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_potrf_n16384_kernel_stats.csv 2>/dev/null || true
 python3 tools/trace_union.py $(find $O/c2_kt -name '*kernel_trace.csv' | head -1) --steps 3 --json $S/${TAG}_potrf_n16384_union.json > /dev/null 2>&1 || true
+ls -la $S
+# round 4: the fp32 factorisation at config 3's size, both routes (operands split once into bf16 planes / split on the fly), kernel stats + counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/f32_kt -o f32 -- python3 tools/f32_presplit_ab.py 65536 > $O/f32_kt.log 2>&1 || true
+cp $(find $O/f32_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_potrf_f32_n65536_kernel_stats.csv 2>/dev/null || true
+grep potrf $O/f32_kt.log > $S/${TAG}_potrf_f32_n65536_ab.txt 2>/dev/null || true
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/f32_sq -o f32 -- python3 tools/f32_presplit_ab.py 32768 > $O/f32_sq.log 2>&1 || true
+python3 tools/pmc_by_kernel.py $O/f32_sq > $S/${TAG}_potrf_f32_n32768_sq.txt 2>&1 || true
 ls -la $S
