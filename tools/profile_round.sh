@@ -35,7 +35,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/grad_kt -o grad -- py
 cp $(find $O/grad_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_grad_n32768_kernel_stats.csv 2>/dev/null || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2_kt -o c2 -- python3 tools/potrf_only.py 16384 > $O/c2_kt.log 2>&1 || true
 cp $(find $O/c2_kt -name '*kernel_stats.csv' | head -1) $S/${TAG}_potrf_n16384_kernel_stats.csv 2>/dev/null || true
-python3 tools/trace_union.py $(find $O/c2_kt -name '*kernel_trace.csv' | head -1) --steps 3 --json $S/${TAG}_potrf_n16384_union.json > /dev/null 2>&1 || true
+python3 tools/trace_union.py $(find $O/c2_kt -name "*kernel_trace.csv" | head -1) --steps 3 --flops-per-step 1.46602e12 --json $S/${TAG}_potrf_n16384_union.json > /dev/null 2>&1 || true
 ls -la $S
 # round 4: the fp32 factorisation at config 3's size, both routes (operands split once into bf16 planes / split on the fly), kernel stats + counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/f32_kt -o f32 -- python3 tools/f32_presplit_ab.py 65536 > $O/f32_kt.log 2>&1 || true
