@@ -191,10 +191,12 @@ int stpy_gemm_nt(int dtype, int64_t m, int64_t n, int64_t k,
                  void* C, int64_t ldc, int mode, int lower_only, void* stream);
 
 /* C (op) A A^T on the lower 128x128 tiles (A: n x k; mode as above): the feature-space normal equations V (+)= Phi_slab^T Phi_slab
- * (kernelized_features.py:236-240, torch.mm(Phi.T, Phi)).  Same result as stpy_gemm_nt(A, A, lower_only = 1), bit for bit.  With a
+ * (kernelized_features.py:236-240, torch.mm(Phi.T, Phi)).  Same result as stpy_gemm_nt(A, A, lower_only = 1).  With a
  * workspace of stpy_syrk_workspace_bytes(dtype, n, k) bytes (0 = the shape has no such route: fp64, n < 2048, n % 128, k % 32) an fp32
  * operand is split ONCE into three bf16 planes (6 bytes per element of A) and every output tile reads those, instead of every tile
- * re-splitting its rows (gemm_bf3p.hip); work may be NULL. */
+ * re-splitting its rows (gemm_bf3p.hip); work may be NULL.  Few output tiles with a long K (modes 0 and 2) are also cut along K into chunks that
+ * run as one grid and are summed in a fixed order (the query then includes the chunk buffers): those results agree with stpy_gemm_nt to fp32
+ * rounding, not bit for bit, and are reproducible from run to run. */
 int64_t stpy_syrk_workspace_bytes(int dtype, int64_t n, int64_t k);
 int stpy_syrk(int dtype, int64_t n, int64_t k, const void* A, int64_t lda, void* C, int64_t ldc, int mode,
               void* work, int64_t work_bytes, void* stream);

@@ -114,7 +114,7 @@ int gemm_splitk_plan(int64_t m, int64_t n, int64_t k);
 // fp32 trailing updates from a panel split once into three bf16 planes (gemm_bf3p.hip): the split pass, and C -= A B^T with A / B = plane rows arow.. / brow..
 int bf3_split(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsigned short* pl, int64_t ldp, int64_t pstride, int64_t prow0, hipStream_t st);
 int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
-                 float* C, int64_t ldc, int tri, hipStream_t st, int mode = 1);
+                 float* C, int64_t ldc, int tri, hipStream_t st, int mode = 1, int nch = 1, float* ws = nullptr);
 int64_t syrk_planes_workspace_bytes(int64_t n, int64_t k);
 int syrk_planes(int64_t n, int64_t k, const float* A, int64_t lda, float* C, int64_t ldc, int mode, void* work, hipStream_t st);
 // bytes of the factorisation's workspace: two panel buffers (look-ahead) and, for fp32, the three bf16 planes of one panel

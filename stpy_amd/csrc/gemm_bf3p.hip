@@ -34,8 +34,14 @@ struct Bf3pArgs {
 	int64_t ldc;
 	int m, n, k;
 	int tri;                        // lower 128 x 128 tiles only (m == n)
-	int nst_m, nst_n, nsuper;       // 1024 x 1024 super-tiles
+	int nst_m, nst_n, nsuper;       // super-tiles of (256 << stl) x (256 << stl) elements
+	int stl;                        // 2: 1024 x 1024 = 4 row pairs x 8 column tiles = 32 workgroups; 1: 512 x 512 = 2 x 4 = 8 workgroups
 	int exp;                        // lab build: timing experiments (results wrong when != 0)
+	// K split over blockIdx.y (few output tiles, long K): chunk c covers K blocks [c * kchunk, ...); chunk 0 applies (op) to C, chunk c >= 1
+	// STORES its partial product to ws + (c - 1) * ws_stride (leading dimension ldws), summed into C afterwards in a fixed order
+	int kchunk;
+	float* ws;
+	int64_t ldws, ws_stride;
 };
 
 // ---- the split: a thread takes 8 consecutive values of a row
@@ -108,8 +114,11 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 
 	// block -> tile: 32 workgroups (4 row pairs x 8 column tiles = 1024 x 1024 elements) of one super-tile share an XCD (b & 7)
 	const int b = blockIdx.x;
-	const int S = (b & 7) + 8 * (b >> 8);
-	const int w = (b >> 3) & 31;
+	// (small problems take 512 x 512 super-tiles: with 36 super-tiles of 1024 x 1024 -- n = 8192, lower triangle -- the XCDs get 116 to 148 tiles
+	// each and the fullest one sets the time: 5 rounds' worth for 4.1 rounds of work)
+	const int wbits = 2 * p.stl + 1;                              // log2(workgroups per super-tile)
+	const int S = (b & 7) + 8 * (b >> (3 + wbits));
+	const int w = (b >> 3) & ((1 << wbits) - 1);
 	if (S >= p.nsuper) return;
 	int si, sj;
 	if (p.tri) {
@@ -121,11 +130,14 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 		si = S / p.nst_n;
 		sj = S - si * p.nst_n;
 	}
-	const int row0 = __builtin_amdgcn_readfirstlane((si * 4 + (w >> 3)) * P_TM);
-	const int col0 = __builtin_amdgcn_readfirstlane((sj * 8 + (w & 7)) * P_TN);
+	const int row0 = __builtin_amdgcn_readfirstlane(((si << p.stl) + (w >> (p.stl + 1))) * P_TM);
+	const int col0 = __builtin_amdgcn_readfirstlane(((sj << (p.stl + 1)) + (w & ((2 << p.stl) - 1))) * P_TN);
 	if (row0 >= p.m || col0 >= p.n) return;
 	if (p.tri && col0 > row0 + 128) return;                       // both 128-row halves lie above the diagonal
-	const int KT = p.k / P_BK;
+	const int chunk = blockIdx.y;
+	const int kbeg = chunk * p.kchunk;
+	const int KT = ((p.k - kbeg < p.kchunk ? p.k - kbeg : p.kchunk)) / P_BK;
+	const bool first_chunk = chunk == 0;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
 	// a wave computes iff its rows exist and its 128 x 128 tile is on or below the diagonal (the tiles gemm_nt_bf3_kernel computes)
@@ -151,7 +163,7 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 		             : "=&s"(keep) : "v"(vo), "s"(gbase), "s"(laddr) : "memory");
 	};
 	auto dma_plane = [&](int stage, int k0, int pt) {
-		const unsigned short* const ub = p.pl + pt * p.pstride + (k0 >> 5) * 512;              // uniform: K block k0 / 32
+		const unsigned short* const ub = p.pl + pt * p.pstride + ((kbeg + k0) >> 5) * 512;              // uniform: K block (kbeg + k0) / 32
 #pragma unroll
 		for (int s = 0; s < 3; ++s)
 			dma_one(ub, voff[s], lds0 + (unsigned)(stage * P_STAGE + pt * P_PLANE + (wave + 8 * s) * 1024));
@@ -164,8 +176,8 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 
 	// ---- accumulators: zero, or the C tile (negated when subtracting: the products are accumulated on -C and the sign flipped at the store)
 	v4f acc[4][4];
-	float* const ctile = p.C + (int64_t)row0 * p.ldc + col0;
-	const unsigned ldc32 = (unsigned)p.ldc;
+	float* const ctile = first_chunk ? p.C + (int64_t)row0 * p.ldc + col0 : p.ws + (int64_t)(chunk - 1) * p.ws_stride + (int64_t)row0 * p.ldws + col0;
+	const unsigned ldc32 = (unsigned)(first_chunk ? p.ldc : p.ldws);
 	if (active) {
 #pragma unroll
 		for (int tm = 0; tm < 4; ++tm)
@@ -173,7 +185,7 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 			for (int i = 0; i < 4; ++i) {
 				const float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
-				for (int tn = 0; tn < 4; ++tn) { const float v = LOADC ? crow[tn * 16] : 0.f; acc[tm][tn][i] = SUB ? -v : v; }
+				for (int tn = 0; tn < 4; ++tn) { const float v = (LOADC && first_chunk) ? crow[tn * 16] : 0.f; acc[tm][tn][i] = SUB ? -v : v; }
 			}
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): stage 0 has landed (and the C tile)
@@ -246,10 +258,13 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 	}
 }
 
+// K split (nch > 1, modes 0 and 5 only): chunk 0 applies (op) to C, chunk c >= 1 stores its partial product into ws[c - 1] (n-leading,
+// m x n floats each); the caller adds them to C in a fixed order (syrk_planes below).
 int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
-                 float* C, int64_t ldc, int tri, hipStream_t st, int mode)
+                 float* C, int64_t ldc, int tri, hipStream_t st, int mode, int nch, float* ws)
 {
 	if (mode != 0 && mode != 1 && mode != 5) { set_error("gemm_nt_bf3p: mode %d", mode); return -11; }
+	if (nch < 1 || nch > 64 || (nch > 1 && (mode == 1 || !ws))) { set_error("gemm_nt_bf3p: K split %d not supported here", nch); return -14; }
 	if (m <= 0 || n <= 0) return 0;
 	if (m % 128 != 0 || n % P_TN != 0 || k % P_BK != 0 || k < P_BK || ldp % 32 != 0 || pstride % 8 != 0 || ((uintptr_t)pl & 15) || (tri && m != n) || arow % 16 != 0 || brow % 16 != 0 ||
 	    m > (1 << 30) || n > (1 << 30) || ldc >= (1 << 24) || ((arow > brow ? arow : brow) + (m > n ? m : n)) * ldp * 2 >= ((int64_t)1 << 32)) {
@@ -259,10 +274,19 @@ int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int6
 	Bf3pArgs p;
 	p.pl = pl; p.ldp = ldp; p.pstride = pstride; p.arow = arow; p.brow = brow; p.C = C; p.ldc = ldc;
 	p.m = (int)m; p.n = (int)n; p.k = (int)k; p.tri = tri ? 1 : 0;
-	p.nst_m = (int)((m + 1023) / 1024); p.nst_n = (int)((n + 1023) / 1024);
+	p.stl = 2;
+	{
+		const int64_t sm = (m + 1023) / 1024, sn = (n + 1023) / 1024;
+		if ((p.tri ? sm * (sm + 1) / 2 : sm * sn) < 128 && !(STPY_LAB && g_potrf_serial_band == -1)) p.stl = 1;          // fewer than 16 super-tiles per XCD: balance before locality (lab: knob 31 = -1 keeps the large ones, for the A/B)
+	}
+	const int64_t se = (int64_t)256 << p.stl;
+	p.nst_m = (int)((m + se - 1) / se); p.nst_n = (int)((n + se - 1) / se);
 	p.nsuper = p.tri ? p.nst_m * (p.nst_m + 1) / 2 : p.nst_m * p.nst_n;
 	p.exp = g_gemm_exp;
-	const int64_t nblocks = (((int64_t)p.nsuper + 7) / 8) * 256;
+	p.kchunk = nch > 1 ? (int)(((k / nch + 127) / 128) * 128) : (int)k;          // whole two-level accumulation chunks (4 K steps of 32)
+	if (nch > 1 && (int64_t)p.kchunk * (nch - 1) >= k) { set_error("gemm_nt_bf3p: K split %d leaves an empty chunk (k = %lld)", nch, (long long)k); return -14; }
+	p.ws = ws; p.ldws = n; p.ws_stride = m * n;
+	const int64_t nblocks = (((int64_t)p.nsuper + 7) / 8) * (8 << (2 * p.stl + 1));
 	if (nblocks > INT32_MAX) { set_error("gemm_nt_bf3p: grid too large"); return -2; }
 	static std::atomic<bool> attr_set{false};
 	if (!attr_set.load(std::memory_order_acquire)) {
@@ -272,18 +296,59 @@ int gemm_nt_bf3p(int64_t m, int64_t n, int64_t k, const unsigned short* pl, int6
 		if (e != hipSuccess) { set_error("gemm_nt_bf3p: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
 		attr_set.store(true, std::memory_order_release);
 	}
-	if (mode == 1) hipLaunchKernelGGL(gemm_bf3p_kernel<1>, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
-	else if (mode == 5) hipLaunchKernelGGL(gemm_bf3p_kernel<2>, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
-	else hipLaunchKernelGGL(gemm_bf3p_kernel<0>, dim3((unsigned)nblocks), dim3(P_THREADS), P_LDS, st, p);
+	const dim3 grid((unsigned)nblocks, (unsigned)nch);
+	if (mode == 1) hipLaunchKernelGGL(gemm_bf3p_kernel<1>, grid, dim3(P_THREADS), P_LDS, st, p);
+	else if (mode == 5) hipLaunchKernelGGL(gemm_bf3p_kernel<2>, grid, dim3(P_THREADS), P_LDS, st, p);
+	else hipLaunchKernelGGL(gemm_bf3p_kernel<0>, grid, dim3(P_THREADS), P_LDS, st, p);
 	return check_launch("gemm_nt_bf3p");
 }
 
 // ---- C (op) A A^T on the lower 128 x 128 tiles, fp32, A split once into the workspace (the feature-space normal equations: every one of the
 // ---- n / 128 row tiles of A is an operand of n / 128 output tiles).  0 bytes = this route does not take the shape.
+// Few output tiles and a long K (m = 8192 features, 65 536 rows per slab: 1056 workgroup tiles = 4.1 rounds on 256 CUs, each 2048 K steps long,
+// so the fifth round runs on an eighth of the chip): the K range is cut into chunks that are dispatched as one grid (blockIdx.y), chunk 0 onto C
+// and the others into their own n x n buffers, which one more launch adds to C in index order -- no workgroup waits for another, the result does
+// not depend on the schedule.  The number of chunks minimises  ceil(tiles * chunks / 256) * (K / chunks)  + a charge per extra buffer.
+static int64_t syrk_tiles(int64_t n)
+{
+	int64_t t = 0;
+	for (int64_t i = 0; i < (n + 255) / 256; ++i) { const int64_t c = 2 * i + 2; t += c < n / 128 ? c : n / 128; }
+	return t;
+}
+
+static int syrk_chunks(int64_t n, int64_t k)
+{
+	const int64_t tiles = syrk_tiles(n);
+	int best = 1;
+	int64_t best_cost = ((tiles + 255) / 256) * k;
+	for (int c = 2; c <= 8; c *= 2) {
+		const int64_t kc = ((k / c + 127) / 128) * 128;
+		if (kc < 4096 || kc * (c - 1) >= k) break;
+		const int64_t cost = ((tiles * c + 255) / 256) * kc + 3000 * (c - 1);
+		if (cost < best_cost - best_cost / 50) { best = c; best_cost = cost; }          // (only for a gain of more than 2 %)
+	}
+	return best;
+}
+
 int64_t syrk_planes_workspace_bytes(int64_t n, int64_t k)
 {
 	if (n % 128 != 0 || n < 2048 || k % P_BK != 0 || k < 2 * P_BK || n * k * 2 >= ((int64_t)1 << 32)) return 0;
-	return 3 * n * k * 2;
+	return 3 * n * k * 2 + (int64_t)(syrk_chunks(n, k) - 1) * n * n * 4;
+}
+
+// C[i][j] += ws[0][i][j] + ws[1][i][j] + ...  on the lower 128 x 128 tiles (fixed order); thread = four consecutive columns
+__global__ __launch_bounds__(256)
+void syrk_chunk_sum_kernel(float* __restrict__ C, int64_t ldc, const float* __restrict__ ws, int64_t n, int nbuf)
+{
+	typedef float v4f __attribute__((ext_vector_type(4)));
+	const int ti = blockIdx.y, tj = blockIdx.x >> 4;            // sixteen workgroups per 128 x 128 tile: 8 rows each
+	if (tj > ti) return;
+	const int r = ti * 128 + (blockIdx.x & 15) * 8 + (threadIdx.x >> 5), c = tj * 128 + (threadIdx.x & 31) * 4;
+	v4f s = *(const v4f*)(ws + (int64_t)r * n + c);
+	for (int b = 1; b < nbuf; ++b) s += *(const v4f*)(ws + (int64_t)b * n * n + (int64_t)r * n + c);
+	float* const o = C + (int64_t)r * ldc + c;
+	if ((((uintptr_t)o) & 15) == 0) *(v4f*)o = *(const v4f*)o + s;
+	else { o[0] += s[0]; o[1] += s[1]; o[2] += s[2]; o[3] += s[3]; }
 }
 
 int syrk_planes(int64_t n, int64_t k, const float* A, int64_t lda, float* C, int64_t ldc, int mode, void* work, hipStream_t st)
@@ -291,7 +356,12 @@ int syrk_planes(int64_t n, int64_t k, const float* A, int64_t lda, float* C, int
 	unsigned short* const pl = (unsigned short*)work;
 	int rc = bf3_split(A, lda, n, k, pl, k, n * k, 0, st);
 	if (rc) return rc;
-	return gemm_nt_bf3p(n, n, k, pl, k, n * k, 0, 0, C, ldc, 1, st, mode);
+	const int nch = mode == 1 ? 1 : syrk_chunks(n, k);
+	float* const ws = (float*)((unsigned char*)work + 3 * n * k * 2);
+	rc = gemm_nt_bf3p(n, n, k, pl, k, n * k, 0, 0, C, ldc, 1, st, mode, nch, nch > 1 ? ws : nullptr);
+	if (rc || nch == 1) return rc;
+	hipLaunchKernelGGL(syrk_chunk_sum_kernel, dim3((unsigned)(n / 128) * 16, (unsigned)(n / 128)), dim3(256), 0, st, C, ldc, (const float*)ws, n, nch - 1);
+	return check_launch("syrk_planes (chunk sum)");
 }
 
 }  // namespace stpy
@@ -302,5 +372,5 @@ extern "C" __attribute__((visibility("default"))) int stpy_debug_bf3_split(const
 { return stpy::bf3_split(X, ldx, rows, cols, (unsigned short*)pl, ldp, pstride, 0, (hipStream_t)stream); }
 extern "C" __attribute__((visibility("default"))) int stpy_debug_gemm_bf3p(int64_t m, int64_t n, int64_t k, const void* pl, int64_t ldp, int64_t pstride, int64_t arow, int64_t brow,
                                                                             float* C, int64_t ldc, int tri, void* stream)
-{ return stpy::gemm_nt_bf3p(m, n, k, (const unsigned short*)pl, ldp, pstride, arow, brow, C, ldc, tri, (hipStream_t)stream, 1); }
+{ return stpy::gemm_nt_bf3p(m, n, k, (const unsigned short*)pl, ldp, pstride, arow, brow, C, ldc, tri, (hipStream_t)stream, 1, 1, nullptr); }
 #endif
