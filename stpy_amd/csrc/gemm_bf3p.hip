@@ -185,11 +185,14 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 			for (int i = 0; i < 4; ++i) {
 				const float* const crow = ctile + ((unsigned)(wm * 64 + tm * 16 + 4 * kq + i) * ldc32 + (unsigned)(wn * 64 + r16));
 #pragma unroll
-				for (int tn = 0; tn < 4; ++tn) { const float v = (LOADC && first_chunk) ? crow[tn * 16] : 0.f; acc[tm][tn][i] = SUB ? -v : v; }
+				for (int tn = 0; tn < 4; ++tn) acc[tm][tn][i] = (LOADC && first_chunk) ? crow[tn * 16] : 0.f;          // (subtracting: negated at the first chunk's addition)
 			}
 	}
-	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): stage 0 has landed (and the C tile)
-	__syncthreads();
+	// stage 0 has landed: its nine DMA instructions are this wave's OLDEST vector-memory operations, the 64 loads of the C tile behind them
+	// may stay in flight (the accumulators are not touched before the end of the first chunk, four K steps from here)
+	if (active && LOADC && first_chunk) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+	else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
 	const unsigned frag = (unsigned)r16 * 64u + (unsigned)((kq ^ ((r16 >> 1) & 3)) << 4);
 	const unsigned a_off = (unsigned)(wm * 64) * 64u + frag, b_off = (unsigned)(P_TM + wn * 64) * 64u + frag;
@@ -243,7 +246,7 @@ void gemm_bf3p_kernel(Bf3pArgs p)
 #pragma unroll
 			for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-				for (int tn = 0; tn < 4; ++tn) acc[tm][tn] += part[tm][tn];
+				for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = (SUB && kc == 0) ? part[tm][tn] - acc[tm][tn] : acc[tm][tn] + part[tm][tn];          // (-C) + p = p - C, bit for bit
 		}
 	}
 	if (active) {
