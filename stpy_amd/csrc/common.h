@@ -29,7 +29,7 @@ extern int g_trsm_right_looking, g_gemm_k128, g_rff_tile, g_trsv_flow, g_trsm_st
 	X(0, g_gemm_stagger, 40000) X(1, g_gemm_exp, 0) X(2, g_potf2_scalar, 0) X(3, g_trsm_pass_depth, 1024) X(4, g_trsm_wg_target, 2048) \
 	X(6, g_gemm_dtv, 1) X(7, g_potrf_diag_first_below, 0) X(10, g_potrf_beside_min, 0) X(11, g_potf2_sliver, 0) \
 	X(12, g_potrf_reserve_below, 0) X(13, g_potrf_reserve_above, 2048) X(14, g_potrf_nb256_upto, 2048) X(15, g_potrf_nb512_upto, 16384) \
-	X(18, g_potrf_strip, 0) X(19, g_rff_wgs, 0) X(20, g_gemm_tri_diag_last, 0) X(21, g_potrf_serial_below, 3200) X(22, g_trsv_fault_ticket, 0) X(23, g_potrf_nb1024_upto, 32768) X(24, g_potrf_first_nb, 0) X(25, g_potrf_nb2048_upto, 1 << 30) X(29, g_potf2_flow, 1) X(31, g_potrf_serial_band, 0)
+	X(18, g_potrf_strip, 0) X(19, g_rff_wgs, 0) X(20, g_gemm_tri_diag_last, 0) X(21, g_potrf_serial_below, 3200) X(22, g_trsv_fault_ticket, 0) X(23, g_potrf_nb1024_upto, 32768) X(24, g_potrf_first_nb, 0) X(25, g_potrf_nb2048_upto, 1 << 30) X(29, g_potf2_flow, 1) X(31, g_potrf_serial_band, 0) X(33, g_potrf_planes_min_tiles, 800)
 STPY_KNOB_LIST(STPY_KNOB)
 constexpr int g_gemm_dtv_min_k = 64;
 // panel width when the caller passes nb = 0: narrower panels shorten the latency-bound panel chain, which a

@@ -1332,21 +1332,25 @@ void gemm_nt_k128_kernel(GemmArgs<double> p)
 //   both operands through LDS-DMA (costs no VGPRs) in a ring of four 16-deep K tiles, one barrier per K tile;
 //   every K tile issues its prefetch unconditionally (clamped to the last tile), so the vmcnt bookkeeping is constant.
 // ------------------------------------------------------------------------------------------
-constexpr int SL_TM = 32, SL_TN = 128, SL_BK = 16, SL_NS = 4;
+constexpr int SL_TM = 32, SL_TN = 128, SL_BK = 16, SL_NS = 4;          // (SL_BK: fp64 values per K tile; a row of a K tile is 128 bytes for both types: 32 fp32 values)
 constexpr int SL_LDS_BYTES = SL_NS * (SL_TM + SL_TN) * SL_BK * 8;          // 80 KiB
 // (dynamic LDS on purpose: with a static 80 KiB array hipcc sees that eight waves per SIMD are out of reach anyway and
 // drops the register cap that amdgpu_waves_per_eu(8, 8) = 64 VGPRs is here to enforce)
-template <bool SUB>
+// (round 4, late: templated on the type -- fp32 takes the few-tile role too; its fp32 MFMA has no negating form, so a subtracting launch
+// accumulates on -C and flips the sign at the store)
+template <typename T, bool SUB>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void gemm_nt_sliver_kernel(GemmArgs<double> p)
+void gemm_nt_sliver_kernel(GemmArgs<T> p)
 {
-	typedef double T;
-	typedef Mfma<double> MM;
-	typedef MM::v4 v4;
-	typedef double d2 __attribute__((ext_vector_type(2)));
+	typedef Mfma<T> MM;
+	typedef typename MM::v4 v4;
+	constexpr int CHE = 16 / (int)sizeof(T);                     // elements per 16-byte chunk: 2 / 4
+	constexpr int BKT = 128 / (int)sizeof(T);                    // elements per K tile: 16 / 32
+	typedef T chunk_t __attribute__((ext_vector_type(CHE)));
+	constexpr bool F64 = sizeof(T) == 8;
 	constexpr int SROWS = SL_TM + SL_TN;                         // rows of one stage: 32 of A, 128 of B, 128 bytes each
 	extern __shared__ __attribute__((aligned(16))) unsigned char sliver_smem_raw[];
-	double* const smem = reinterpret_cast<double*>(sliver_smem_raw);
+	T* const smem = reinterpret_cast<T*>(sliver_smem_raw);
 #ifdef STPY_STAMPS
 	unsigned long long stamp[5];
 	stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -1367,15 +1371,15 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 	if (p.C2) p.C2 += cb * SL_TN;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, g = lane >> 4;
-	const int KT = p.k / SL_BK;
+	const int KT = p.k / BKT;
 
 	// ---- LDS-DMA: a stage is 20 pieces of 8 rows (1 KiB); wave w moves piece w (A rows 8w..) and pieces w + 4i (B rows
 	// ---- 8w + 32(i-1)..), i = 1..4.  Piece parity = w & 1 for all five, so one swizzle term serves them; addresses are a
 	// ---- uniform 64-bit base (SGPRs) plus one 32-bit lane offset per operand.
 	const int rl = lane >> 3;
 	const int fsrc = (((rl >> 1) & 3) << 1) | (wave & 1);
-	const unsigned alane = ((unsigned)rl * (unsigned)p.lda + (unsigned)(((lane & 7) ^ fsrc) * 2)) * 8u;
-	const unsigned blane = ((unsigned)rl * (unsigned)p.ldb + (unsigned)(((lane & 7) ^ fsrc) * 2)) * 8u;
+	const unsigned alane = ((unsigned)rl * (unsigned)p.lda + (unsigned)(((lane & 7) ^ fsrc) * CHE)) * (unsigned)sizeof(T);
+	const unsigned blane = ((unsigned)rl * (unsigned)p.ldb + (unsigned)(((lane & 7) ^ fsrc) * CHE)) * (unsigned)sizeof(T);
 	const T* const abase = p.A + (int64_t)(row0 + 8 * wave) * p.lda;
 	const T* const bbase = p.B + (int64_t)(8 * wave) * p.ldb;
 	const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) T*)smem;
@@ -1385,7 +1389,7 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 		             : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(laddr) : "memory");
 	};
 	auto dma_stage = [&](int kt) {                               // K tile kt (clamped) into ring slot kt % NS
-		const int k0 = min(kt, KT - 1) * SL_BK;
+		const int k0 = min(kt, KT - 1) * BKT;
 		const unsigned base = lds0 + (unsigned)((kt & (SL_NS - 1)) * SROWS) * 128u;
 		dma_one(abase + k0, alane, base + (unsigned)(8 * wave) * 128u);
 #pragma unroll
@@ -1402,12 +1406,14 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 	T* const ctile = p.C + (int64_t)(row0 + wm * 16) * p.ldc + wn * 64;          // uniform
 	// (byte offsets in 32 bits, so that every access is  global_load/store v, v_off, s[base:base+1] offset:imm  and no 64-bit
 	// per-lane address has to stay alive across the K loop -- with 64 VGPRs those went to scratch)
-	const unsigned clane = ((unsigned)g * (unsigned)p.ldc + (unsigned)r16) * 8u;
+	// (fp32: register i is row 4 (lane >> 4) + i)
+	constexpr int RSTEP = F64 ? 4 : 1, GMUL = F64 ? 1 : 4, CTB = 16 * (int)sizeof(T);          // row step per register, row step per lane group, bytes per column tile
+	const unsigned clane = ((unsigned)(g * GMUL) * (unsigned)p.ldc + (unsigned)r16) * (unsigned)sizeof(T);
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		const char* const ci = (const char*)(ctile + (int64_t)(4 * i) * p.ldc);  // uniform
+		const char* const ci = (const char*)(ctile + (int64_t)(RSTEP * i) * p.ldc);  // uniform
 #pragma unroll
-		for (int t = 0; t < 4; ++t) acc[t][i] = SUB ? *(const T*)(ci + clane + t * 128) : T(0);
+		for (int t = 0; t < 4; ++t) { const T v = SUB ? *(const T*)(ci + clane + t * CTB) : T(0); acc[t][i] = (SUB && !F64) ? -v : v; }
 	}
 	__builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
 	__syncthreads();
@@ -1416,7 +1422,7 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 #endif
 
 	const int fsw = (((r16 >> 1) & 3) << 1) | ((r16 >> 3) & 1);
-	const int aoff = (wm * 16 + r16) * SL_BK, boff = (SL_TM + wn * 64 + r16) * SL_BK;
+	const int aoff = (wm * 16 + r16) * BKT, boff = (SL_TM + wn * 64 + r16) * BKT;
 	for (int kt = 0; kt < KT; ++kt) {
 		if (kt > 0) {
 			// tiles kt+1 and kt+2 (ten pieces of this wave) may still be in flight; tile kt has landed
@@ -1424,16 +1430,16 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 			__syncthreads();                     // ... for every wave, and everybody has finished reading tile kt-1
 		}
 		dma_stage(kt + 3);                       // into the slot tile kt-1 occupied
-		const T* st = smem + (kt & (SL_NS - 1)) * SROWS * SL_BK;
+		const T* st = smem + (kt & (SL_NS - 1)) * SROWS * BKT;
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
-			const int off = ((2 * g + h) ^ fsw) * 2;
-			const d2 fa = *(const d2*)(st + aoff + off);
+			const int off = ((2 * g + h) ^ fsw) * CHE;
+			const chunk_t fa = *(const chunk_t*)(st + aoff + off);
 #pragma unroll
 			for (int t = 0; t < 4; ++t) {
-				const d2 fb = *(const d2*)(st + boff + t * 16 * SL_BK + off);
+				const chunk_t fb = *(const chunk_t*)(st + boff + t * 16 * BKT + off);
 #pragma unroll
-				for (int s2 = 0; s2 < 2; ++s2) acc[t] = SUB ? MM::mms(fa[s2], fb[s2], acc[t]) : MM::mma(fa[s2], fb[s2], acc[t]);
+				for (int s2 = 0; s2 < CHE; ++s2) acc[t] = (SUB && F64) ? MM::mms(fa[s2], fb[s2], acc[t]) : MM::mma(fa[s2], fb[s2], acc[t]);
 			}
 		}
 	}
@@ -1449,18 +1455,18 @@ void gemm_nt_sliver_kernel(GemmArgs<double> p)
 #endif
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		char* const ci = (char*)(ctile + (int64_t)(4 * i) * p.ldc);
+		char* const ci = (char*)(ctile + (int64_t)(RSTEP * i) * p.ldc);
 #pragma unroll
-		for (int t = 0; t < 4; ++t) *(T*)(ci + clane + t * 128) = acc[t][i];
+		for (int t = 0; t < 4; ++t) *(T*)(ci + clane + t * CTB) = (SUB && !F64) ? -acc[t][i] : acc[t][i];
 	}
 	if (p.C2) {
 		T* const c2tile = p.C2 + (int64_t)(row0 + wm * 16) * p.ldc2 + wn * 64;
-		const unsigned c2lane = ((unsigned)g * (unsigned)p.ldc2 + (unsigned)r16) * 8u;
+		const unsigned c2lane = ((unsigned)(g * GMUL) * (unsigned)p.ldc2 + (unsigned)r16) * (unsigned)sizeof(T);
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			char* const ci = (char*)(c2tile + (int64_t)(4 * i) * p.ldc2);
+			char* const ci = (char*)(c2tile + (int64_t)(RSTEP * i) * p.ldc2);
 #pragma unroll
-			for (int t = 0; t < 4; ++t) *(T*)(ci + c2lane + t * 128) = acc[t][i];
+			for (int t = 0; t < 4; ++t) *(T*)(ci + c2lane + t * CTB) = (SUB && !F64) ? -acc[t][i] : acc[t][i];
 		}
 	}
 #ifdef STPY_STAMPS
@@ -1669,30 +1675,35 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 	                     (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
 	const dim3 grid((unsigned)nblocks), block(NTHREADS);
 #define STPY_LAUNCH(G, S, E) hipLaunchKernelGGL((gemm_nt_kernel<T, G, S, E>), grid, block, 0, st, p)
-	if constexpr (sizeof(T) == 8) {
-		// panel-chain products enqueued beside a trailing update (see gemm_nt_sliver_kernel)
-		// ... and (round 4, route key 30) plain / lower-only products of few 128 x 128 tiles with K >= 64: see the kernel
+	{
+		// panel-chain products enqueued beside a trailing update (see gemm_nt_sliver_kernel; fp64 only: beside the fp32 update's 144 KiB workgroups
+		// nothing else fits on a CU)
+		// ... and (round 4, route key 30) plain / lower-only products of few 128 x 128 tiles with K >= 64, both types: see the kernel
+		constexpr int CHE = 16 / (int)sizeof(T), BKT = 128 / (int)sizeof(T);
 		const int64_t sl_tiles = p.tri ? (int64_t)p.tiles_m * (p.tiles_m + 1) / 2 : (int64_t)p.tiles_m * p.tiles_n;
-		const bool sl_beside = (gflags & GEMM_BESIDE) && n == SL_TN && !lower_only;
+		const bool sl_beside = sizeof(T) == 8 && (gflags & GEMM_BESIDE) && n == SL_TN && !lower_only;
 		// (crossover, tools/sliver_vs_tile.py + tools/potrf_sweep.py "30=...": lower-triangular updates up to ~3200 tiles, i.e. 10 000 rows, at every
 		// K = 128 .. 2048 -- 4.8x at 36 tiles, 1.7x at 136, 1.3-1.4x at 528, par at 2080, 0.93x at 4656; rectangles with a long K, the block solve's
 		// products, turn earlier: half the threshold)
 		const bool sl_few = g_gemm_sliver_tiles > 0 && sl_tiles <= (p.tri ? g_gemm_sliver_tiles : g_gemm_sliver_tiles / 2) && (n % SL_TN == 0) && k >= 64 && (!lower_only || p.tri == 1) && lower_only != 2 && n / SL_TN <= 65535;
-		if ((sl_beside || sl_few) && (m % SL_TM == 0) && (k % SL_BK == 0) && k >= SL_BK && (mode == 0 || mode == 1) && !bc &&
-		    p.ksplit == 1 && !g_gemm_exp && (lda % 2 == 0) && (ldb % 2 == 0) && lda < (1 << 24) && ldb < (1 << 24) && ldc < ((int64_t)1 << 28) && ldc2 < ((int64_t)1 << 28) &&
+		if ((sl_beside || sl_few) && (m % SL_TM == 0) && (k % BKT == 0) && k >= BKT && (mode == 0 || mode == 1) && !bc &&
+		    p.ksplit == 1 && !g_gemm_exp && (lda % CHE == 0) && (ldb % CHE == 0) && lda < (1 << 24) && ldb < (1 << 24) && ldc < ((int64_t)1 << 25) && ldc2 < ((int64_t)1 << 25) &&
 		    (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {
-			static std::atomic<bool> attr_set{false};
-			if (!attr_set.load(std::memory_order_acquire)) {
-				hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_sliver_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES);
-				if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_sliver_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES);
+			static std::atomic<bool> attr_set[2];
+			constexpr int which = sizeof(T) == 8 ? 0 : 1;
+			if (!attr_set[which].load(std::memory_order_acquire)) {
+				hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_sliver_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES);
+				if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_nt_sliver_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES);
 				if (e != hipSuccess) { set_error("gemm_nt (sliver): hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return -1000 - (int)e; }
-				attr_set.store(true, std::memory_order_release);
+				attr_set[which].store(true, std::memory_order_release);
 			}
 			const dim3 gs((unsigned)(m / SL_TM), (unsigned)(n / SL_TN));
-			if (mode == 1) hipLaunchKernelGGL((gemm_nt_sliver_kernel<true>), gs, block, SL_LDS_BYTES, st, p);
-			else hipLaunchKernelGGL((gemm_nt_sliver_kernel<false>), gs, block, SL_LDS_BYTES, st, p);
+			if (mode == 1) hipLaunchKernelGGL((gemm_nt_sliver_kernel<T, true>), gs, block, SL_LDS_BYTES, st, p);
+			else hipLaunchKernelGGL((gemm_nt_sliver_kernel<T, false>), gs, block, SL_LDS_BYTES, st, p);
 			return check_launch("gemm_nt (sliver)");
 		}
+	}
+	if constexpr (sizeof(T) == 8) {
 		// the panel chain's K = 128 products (see gemm_nt_k128_kernel)
 		const int64_t t64 = ((m + 63) / 64) * (n / 64);
 		if (g_gemm_k128 && !(gflags & GEMM_BESIDE) && k == 128 && (n % 128 == 0) && (mode == 0 || mode == 1) && !lower_only && !bc && p.ksplit == 1 && !g_gemm_exp &&

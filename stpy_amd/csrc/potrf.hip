@@ -1351,7 +1351,12 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 	// trailing update C[r0:n, r0:r0+cols] -= Pk[r0:n] Pk[r0:r0+cols]^T  (lower: cols = n - r0, lower tiles only), from the planes when `pre`
 	auto update = [&](T* Pk, bool pre, int64_t r0, int64_t cols, int64_t kk, int lower) -> int {
 		if constexpr (sizeof(T) == 4) {
-			if (pre && ((n - r0) / 128) * (cols / 128) >= (lower ? 128 : 64))
+			// (few tiles: the 32 x 128 slivers of gemm_nt on the fp32 MFMA are as fast or faster.  Lab knob 33 = the tile count above which the planes
+			// take a lower-triangular update, tools/potrf_sweep.py "33=128|800|1600|3200|5000": N = 8192 4.50 / 4.43 / 4.45 / 4.44 / 4.43 ms,
+			// 16 384 13.87 / 13.86 / 14.08 / 14.51 / 14.67, 32 768 64.9 / 65.0 / 65.1 / 67.1 / 67.4 -> 800 tiles, i.e. ~5000 rows)
+			const int64_t t = (n - r0) / 128, tiles = lower ? t * (t + 1) / 2 : t * (cols / 128);
+			const int64_t floor_t = g_gemm_sliver_tiles > 0 ? g_potrf_planes_min_tiles : 0;          // (slivers switched off: the planes from 128 / 64 tiles on)
+			if (pre && tiles >= (lower ? 128 : 64) && tiles > (lower ? floor_t : floor_t / 2))
 				return gemm_nt_bf3p(n - r0, cols, kk, planes, ldp, pstride, r0, r0, (float*)A + r0 * lda + r0, lda, lower, U);
 		}
 		return gemm_nt<T>(n - r0, cols, kk, Pk + r0 * ldp, ldp, Pk + r0 * ldp, ldp, A + r0 * lda + r0, lda, (T*)nullptr, 0, 1, lower, U);
@@ -1371,7 +1376,7 @@ int potrf(int64_t n, T* A, int64_t lda, T* winv, T* work, int nb, int32_t* info,
 		if (rc) return rc;
 		bool pre = false;
 		if constexpr (sizeof(T) == 4) {
-			pre = g_potrf_presplit && (n - r) % 128 == 0 && (n - r) >= 2048 && wk % 32 == 0 && wk >= 64 && nkb % 128 == 0 && lda < (1 << 24) &&
+			pre = g_potrf_presplit && (n - r) % 128 == 0 && (n - r) >= 2048 && ((n - r) / 128) * ((n - r) / 128 + 1) / 2 > (g_gemm_sliver_tiles > 0 ? g_potrf_planes_min_tiles : 0) && wk % 32 == 0 && wk >= 64 && nkb % 128 == 0 && lda < (1 << 24) &&
 			      (((uintptr_t)Pk | (uintptr_t)planes) & 15) == 0 && n * ldp * 2 < ((int64_t)1 << 32);
 			if (pre) {
 				rc = bf3_split((const float*)Pk + r * ldp, ldp, n - r, wk, planes, ldp, pstride, r, U);

@@ -53,7 +53,13 @@ def test_syrk_from_planes_is_bit_identical_to_gemm_nt(L, n, k, lda_pad):
 	ref64 = A.double() @ A.double().T
 	for mode in (0, 1, 2):
 		Ca, Cb = C0.clone(), C0.clone()
-		L.check(lib.stpy_gemm_nt(L.F32, n, n, k, L.ptr(A), lda, L.ptr(A), lda, L.ptr(Ca), n, mode, 1, L.stream_ptr()), "gemm")
+		# (the comparison is with the on-the-fly bf16 split: the few-tile sliver route, which would take these small products onto the fp32 MFMA, is off)
+		keep30 = int(lib.stpy_tune_get(30))
+		lib.stpy_tune(30, 0)
+		try:
+			L.check(lib.stpy_gemm_nt(L.F32, n, n, k, L.ptr(A), lda, L.ptr(A), lda, L.ptr(Ca), n, mode, 1, L.stream_ptr()), "gemm")
+		finally:
+			lib.stpy_tune(30, keep30)
 		L.check(lib.stpy_syrk(L.F32, n, k, L.ptr(A), lda, L.ptr(Cb), n, mode, L.ptr(work), wb, L.stream_ptr()), "syrk")
 		torch.cuda.synchronize()
 		if nbuf == 0 or mode == 1:
@@ -71,7 +77,7 @@ def test_syrk_from_planes_is_bit_identical_to_gemm_nt(L, n, k, lda_pad):
 	L.check(lib.stpy_syrk(L.F32, n, k, L.ptr(A), lda, L.ptr(Cc), n, 1, None, 0, L.stream_ptr()), "syrk")
 	Cd = C0.clone()
 	L.check(lib.stpy_gemm_nt(L.F32, n, n, k, L.ptr(A), lda, L.ptr(A), lda, L.ptr(Cd), n, 1, 1, L.stream_ptr()), "gemm")
-	assert torch.equal(Cc[low], Cd[low])
+	assert torch.equal(Cc[low], Cd[low])                          # (same routing rules for both entry points)
 	assert int(lib.stpy_syrk_workspace_bytes(L.F64, n, k)) == 0 and int(lib.stpy_syrk_workspace_bytes(L.F32, 1920, k)) == 0
 	A64 = torch.randn(300, 70, dtype=torch.float64, device="cuda:0")
 	C64 = torch.zeros(300, 300, dtype=torch.float64, device="cuda:0")
@@ -387,6 +393,43 @@ def test_gemm_nt_lower_only(L, n, k):
 			assert np.array_equal(out[blk], C[blk])
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-13), (torch.float32, 3e-6)])
+@pytest.mark.parametrize("m,n,k,lower,pad", [(1024, 1024, 256, 1, 0), (2048, 2048, 96 + 32, 1, 4), (640, 384, 64, 0, 0), (1536, 512, 1024, 0, 8), (3072, 3072, 512, 1, 0)])
+def test_gemm_nt_few_tile_sliver_route(L, dtype, tol, m, n, k, lower, pad):
+	"""Route key 30: plain / lower-only products of few 128 x 128 tiles run as 32 x 128 slivers (four times the workgroups), in fp64 and --
+	round 4 -- in fp32 (fp32 MFMA, accumulating on -C when subtracting).  Both modes against an fp64 product, the route switched off against
+	it switched on, operands inside padded buffers, tiles above the diagonal untouched."""
+	lib = L.load()
+	code = L.dtype_code(dtype)
+	torch.manual_seed(m + n + k)
+	Ab = torch.randn(m, k + pad, dtype=dtype, device="cuda:0")
+	Bb = Ab if lower else torch.randn(n, k + pad, dtype=dtype, device="cuda:0")
+	A, B = Ab[:, :k], Bb[:, :k]
+	C0 = torch.randn(m, n + pad, dtype=dtype, device="cuda:0")
+	ref = A.double() @ B.double().T
+	keep = int(lib.stpy_tune_get(30))
+	assert keep > 0
+	outs = {}
+	try:
+		for route in (keep, 0):
+			lib.stpy_tune(30, route)
+			for mode in (0, 1):
+				Cd = C0.clone()
+				L.check(lib.stpy_gemm_nt(code, m, n, k, L.ptr(A), k + pad, L.ptr(B), k + pad, L.ptr(Cd), n + pad, mode, lower, L.stream_ptr()), "gemm")
+				outs[(route, mode)] = Cd
+	finally:
+		lib.stpy_tune(30, keep)
+	mask = torch.ones(m, n, dtype=torch.bool, device="cuda:0")
+	if lower:
+		mask = torch.ones(m // 128, n // 128, device="cuda:0").tril().bool().repeat_interleave(128, 0).repeat_interleave(128, 1)
+	for mode in (0, 1):
+		want = ref if mode == 0 else C0[:, :n].double() - ref
+		for route in (keep, 0):
+			got = outs[(route, mode)]
+			assert float((got[:, :n].double() - want)[mask].abs().max()) < tol * float(want.abs().max()) * (k ** 0.5), (route, mode)
+			assert torch.equal(got[:, :n][~mask], C0[:, :n][~mask]) and torch.equal(got[:, n:], C0[:, n:])
+
+
 def test_gemm_nt_strided_submatrix(L):
 	"""Leading dimensions larger than the logical width, operands inside bigger buffers."""
 	rng = np.random.RandomState(5)
@@ -610,6 +653,8 @@ def test_f32_factor_presplit_route_is_bit_identical(L):
 	K = np.exp(-0.5 * np.maximum(xx[:, None] + xx[None, :] - 2 * x @ x.T, 0) / 0.3 ** 2) + 0.05 * np.eye(n)
 	assert lib.stpy_tune_get(32) == 1
 	outs = []
+	keep30 = int(lib.stpy_tune_get(30))
+	lib.stpy_tune(30, 0)          # (with the few-tile route on, route 0 would take its mid-size updates onto the fp32 MFMA: a different comparison)
 	try:
 		for route in (0, 1):
 			lib.stpy_tune(32, route)
@@ -618,6 +663,7 @@ def test_f32_factor_presplit_route_is_bit_identical(L):
 			outs.append((torch.tril(Ld).clone(), winv.clone()))
 	finally:
 		lib.stpy_tune(32, 1)
+		lib.stpy_tune(30, keep30)
 	assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 	Lref = np.linalg.cholesky(K)
 	assert rel_err(outs[1][0].cpu().numpy().astype(np.float64), Lref) < 2e-5

@@ -8,6 +8,7 @@ sys.path.insert(0, ".")
 from stpy_amd import _lib as L
 
 lib = L.load()
+lib.stpy_tune(30, 0)          # the few-tile sliver route off: route 0 is then the on-the-fly bf16 split at every size (the bit-for-bit comparison)
 dev = torch.device("cuda:0")
 ns = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "8192,16384,32768,65536").split(",")]
 DIAG = len(sys.argv) > 2 and sys.argv[2] == "diag"          # K = 4 I: every panel is zero below its diagonal block -> all-zero operands in the updates (clock / power probe)
