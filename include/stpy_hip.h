@@ -304,7 +304,7 @@ int stpy_async_status(void* stream);
  *      from an exact three-way split of both operands (64; 0 = always the fp32 MFMA kernels)
  *   28 fp64 Gram fill: 1 = the dedicated fill kernel for aligned overwriting fills (three small workgroups per CU), 0 = always the
  *      fused epilogue of the MFMA GEMM
- *   30 fp64 products: plain / lower-only products of at most this many 128 x 128 tiles (and K >= 64) run as 32 x 128 slivers, four
+ *   30 plain / lower-only products (both types) of at most this many 128 x 128 tiles (and K >= 64) run as 32 x 128 slivers, four
  *      times the workgroups of the tile kernels (3200; 0 = never) -- the small trailing updates at the end of every factorisation
  *   32 fp32 factorisation: 1 = each finished panel is split ONCE into three bf16 planes in the workspace and its trailing updates of
  *      2048 rows and more run from those planes (gemm_bf3p.hip); 0 = every tile of an update splits its operands on the fly (key 26's
