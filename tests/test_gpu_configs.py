@@ -10,6 +10,8 @@ size-independent properties:
                                                4096-point sub-problem
   C5  RFF N = 262 144, d = 64, m = 32 768, fp32 : sampled rows of the first / middle / last row blocks, every one of the
                                                eight W-eighths (all columns), against the oracle (2e-5 of the amplitude)
+  KF  KernelizedFeatures N = 262 144, d = 64, m = 8192, fp32 (the bench's streaming shape): sampled entries of Phi^T Phi and Phi^T y
+      against fp64 sums over all rows, the normal-equation residual
   C*  the headline N = 65 536 fp64: test_gpu_gp.py::test_headline_size_properties (identities) and, here, the FACTOR itself against
       the oracle: its leading 16 384 x 16 384 block against the oracle's Cholesky of the leading sub-Gram, and sampled rows of
       L L^T - (K + s^2 I) from the trailing part
@@ -142,6 +144,49 @@ def test_config5_full_size_rff(S):
 	rs = (z[::4096].double() ** 2).sum(dim=1)
 	assert float((rs - 1.0).abs().max()) < 0.05
 	del z
+	_free()
+
+
+def test_kernelized_features_full_shape_properties(S):
+	"""The bench's KernelizedFeatures shape at FULL size (N = 262 144, d = 64, m = 8192 random Fourier features, fp32, four 2 GiB slabs):
+	the accumulated normal equations and their solution through size-independent properties, checked with torch in fp64 (checker only):
+	  * sampled entries of V_acc = Phi^T Phi (lower tiles; rows from every slab, feature indices from the first / a middle / the last
+	    128-tile) against an fp64 sum over ALL rows of the embedding recomputed row block by row block;
+	  * Phi^T y likewise;
+	  * the solution: || (V_acc_sym + s^2 lam I) theta - Phi^T y || / || Phi^T y ||  (the m x m fp32 factorisation + both vector solves)."""
+	from stpy_amd.continuous_processes.kernelized_features import KernelizedFeatures
+	n, d, m = 262144, 64, 8192
+	x = torch.rand(n, d, generator=torch.Generator().manual_seed(1238), dtype=torch.float32).cuda()
+	y = (torch.sin(x[:, :4].sum(dim=1, keepdim=True)) + 0.1 * torch.randn(n, 1, generator=torch.Generator().manual_seed(1239), dtype=torch.float32).cuda())
+	np.random.seed(1238)
+	emb = S.RFFEmbedding(gamma=math.sqrt(d), m=m, d=d)
+	emb.W = emb.W.float()
+	kf = KernelizedFeatures(embedding=emb, m=m, s=1.0, lam=1.0, d=d)
+	kf.fit_gp(x, y)
+	V = kf._Vacc
+	assert tuple(V.shape) == (m, m) and V.dtype == torch.float32
+	fi = torch.tensor([0, 1, 127, 128, 4095, 4096, 4100, 8063, 8064, 8191], device="cuda:0")
+	acc = torch.zeros(len(fi), len(fi), dtype=torch.float64, device="cuda:0")
+	rhs = torch.zeros(len(fi), dtype=torch.float64, device="cuda:0")
+	for r0 in range(0, n, 32768):
+		ph = emb.embed(x[r0:r0 + 32768])[:, fi].double()          # (rows, 10)
+		acc += ph.T @ ph
+		rhs += (ph * y[r0:r0 + 32768].double()).sum(dim=0)
+		del ph
+	got = V[fi][:, fi].double()
+	low = torch.ones(len(fi), len(fi), device="cuda:0").tril().bool()          # (fi is increasing: i >= j is on or below the diagonal tile)
+	scale = float(acc.diagonal().max())
+	e_v = float((got - acc)[low].abs().max()) / scale
+	e_r = float((kf._rhs.reshape(-1)[fi].double() - rhs).abs().max()) / max(float(rhs.abs().max()), 1.0)
+	# the solution against the symmetrised accumulator in fp64
+	Vs = torch.tril(V).double()
+	Vs = Vs + torch.tril(Vs, -1).T + torch.eye(m, dtype=torch.float64, device="cuda:0") * (kf.s ** 2 * kf.lam)
+	th = kf._theta.reshape(-1).double()
+	b = kf._rhs.reshape(-1).double()
+	e_s = float(torch.linalg.norm(Vs @ th - b) / torch.linalg.norm(b))
+	print("KF full shape: V entries %.2e of the diagonal, Phi^T y %.2e, normal-equation residual %.2e" % (e_v, e_r, e_s))
+	assert e_v < 2e-6 and e_r < 2e-6 and e_s < 2e-5          # (measured 4.5e-7 / 7e-8 / 3.6e-7)
+	del Vs
 	_free()
 
 
