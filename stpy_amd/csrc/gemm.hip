@@ -1685,7 +1685,10 @@ int gemm_nt(int64_t m, int64_t n, int64_t k, const T* A, int64_t lda, const T* B
 		// (crossover, tools/sliver_vs_tile.py + tools/potrf_sweep.py "30=...": lower-triangular updates up to ~3200 tiles, i.e. 10 000 rows, at every
 		// K = 128 .. 2048 -- 4.8x at 36 tiles, 1.7x at 136, 1.3-1.4x at 528, par at 2080, 0.93x at 4656; rectangles with a long K, the block solve's
 		// products, turn earlier: half the threshold)
-		const bool sl_few = g_gemm_sliver_tiles > 0 && sl_tiles <= (p.tri ? g_gemm_sliver_tiles : g_gemm_sliver_tiles / 2) && (n % SL_TN == 0) && k >= 64 && (!lower_only || p.tri == 1) && lower_only != 2 && n / SL_TN <= 65535;
+		// (fp32 rectangles: an eighth -- above ~400 tiles the bf16-split tile kernel, whose pipe is 2.6x the fp32 MFMA's, is ahead again: block solve
+		// n = 65 536 fp32, M = 256 / 1024 / 4096 rows: 19.6 / 35.8 / 99.4 ms without slivers, 16.2 / 34.7 / 102.8 with the fp64 rule)
+		const int64_t sl_rect = sizeof(T) == 4 ? g_gemm_sliver_tiles / 8 : g_gemm_sliver_tiles / 2;
+		const bool sl_few = g_gemm_sliver_tiles > 0 && sl_tiles <= (p.tri ? g_gemm_sliver_tiles : sl_rect) && (n % SL_TN == 0) && k >= 64 && (!lower_only || p.tri == 1) && lower_only != 2 && n / SL_TN <= 65535;
 		if ((sl_beside || sl_few) && (m % SL_TM == 0) && (k % BKT == 0) && k >= BKT && (mode == 0 || mode == 1) && !bc &&
 		    p.ksplit == 1 && !g_gemm_exp && (lda % CHE == 0) && (ldb % CHE == 0) && lda < (1 << 24) && ldb < (1 << 24) && ldc < ((int64_t)1 << 25) && ldc2 < ((int64_t)1 << 25) &&
 		    (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0)) {

@@ -19,7 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/gr_write -o gr -- python3 t
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/gr_fetch -o gr -- python3 tools/gram_rff_only.py > $O/gr_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/gr_sq -o gr -- python3 tools/gram_rff_only.py > $O/gr_sq.log 2>&1 || exit 1
 # summaries for profiles/ (copied into the tracked directory by hand after the call)
-TAG=${1:-r04_f}
+TAG=${1:-r04_g}
 S=$O/summaries; mkdir -p $S
 f=$(find $O/kt -name '*kernel_trace.csv' | head -1)
 python3 tools/trace_union.py $f --steps 4 --json $S/${TAG}_bench_n65536_union.json > $S/${TAG}_union.txt 2>&1
